@@ -1,0 +1,257 @@
+"""Synthetic, seeded inputs of the benchmark's shape (numpy only; no dataset or weights are
+available offline - SURVEY.md 8(d)): a procedural mustard-like bottle mesh, an RGB-D frame around
+it, and reference-layout state_dicts with seeded random parameters.
+
+Nothing here is on the hot path; bench.py and the tests use it to build identical inputs.
+"""
+import math
+import numpy as np
+import torch
+
+YCB_K = np.array([[1066.778, 0.0, 312.9869], [0.0, 1067.487, 241.3109], [0.0, 0.0, 1.0]], dtype=np.float64)
+
+
+class _Visual:
+  def __init__(self, vertex_colors):
+    self.vertex_colors = vertex_colors        # (V,4) uint8, trimesh ColorVisuals convention
+
+
+class TextureVisual:
+  """Stand-in for trimesh.visual.texture.TextureVisuals: `.uv` (V,2), `.image` (Ht,Wt,3) uint8."""
+  def __init__(self, uv, image):
+    self.uv = uv
+    self.image = image
+
+
+class SimpleMesh:
+  """Minimal duck-type of the trimesh.Trimesh attributes the hot path reads
+  (src/estimater.py:44-51, src/Utils.py:104-130): vertices, faces, vertex_normals, visual, copy()."""
+
+  def __init__(self, vertices, faces, vertex_normals=None, vertex_colors=None, visual=None):
+    self.vertices = np.asarray(vertices, dtype=np.float64)
+    self.faces = np.asarray(faces, dtype=np.int64)
+    self._vn = None if vertex_normals is None else np.asarray(vertex_normals, dtype=np.float64)
+    if visual is not None:
+      self.visual = visual
+    else:
+      if vertex_colors is None:
+        vertex_colors = np.tile(np.array([128, 128, 128, 255], dtype=np.uint8), (len(self.vertices), 1))
+      self.visual = _Visual(np.asarray(vertex_colors, dtype=np.uint8))
+
+  @property
+  def vertex_normals(self):
+    if self._vn is None:
+      self._vn = angle_weighted_vertex_normals(self.vertices, self.faces)
+    return self._vn
+
+  def copy(self):
+    m = SimpleMesh(self.vertices.copy(), self.faces.copy(), None if self._vn is None else self._vn.copy(), visual=self.visual)
+    return m
+
+
+def angle_weighted_vertex_normals(v, f):
+  """Face normals accumulated per vertex with face-angle weights, normalised (trimesh's
+  `vertex_normals` convention)."""
+  v = np.asarray(v, dtype=np.float64)
+  tri = v[f]
+  fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+  fn /= np.maximum(np.linalg.norm(fn, axis=1, keepdims=True), 1e-20)
+  out = np.zeros_like(v)
+  for k in range(3):
+    a = tri[:, (k + 1) % 3] - tri[:, k]
+    b = tri[:, (k + 2) % 3] - tri[:, k]
+    cosang = (a * b).sum(1) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-20)
+    ang = np.arccos(np.clip(cosang, -1, 1))
+    np.add.at(out, f[:, k], fn * ang[:, None])
+  out /= np.maximum(np.linalg.norm(out, axis=1, keepdims=True), 1e-20)
+  return out
+
+
+def make_mustard_mesh(seed=0, n_theta=96, n_z=84, textured=False):
+  """Closed bottle: super-elliptic cross-section swept along z with a body / shoulder / neck / cap
+  profile; extents ~0.095 x 0.058 x 0.19 m; 8066 verts / 16128 faces at the defaults."""
+  rs = np.random.RandomState(seed)
+  zs = np.linspace(0.0, 1.0, n_z)
+
+  def profile(t):
+    body = 1.0 - 0.06 * np.cos(2 * np.pi * t * 1.3)
+    shoulder = 1.0 / (1.0 + np.exp((t - 0.70) * 28.0))
+    neck = 0.30 + 0.05 * (t > 0.9)
+    r = neck + (body - neck) * shoulder
+    r = r * np.minimum(1.0, np.sqrt(np.maximum(t, 0) / 0.04 + 1e-9))      # rounded bottom
+    r = r * np.minimum(1.0, np.sqrt(np.maximum(1.0 - t, 0) / 0.02 + 1e-9))  # rounded cap
+    return r
+  r = profile(zs)
+  th = np.linspace(0, 2 * np.pi, n_theta, endpoint=False)
+  n_exp = 2.6
+  cx = np.sign(np.cos(th)) * np.abs(np.cos(th)) ** (2.0 / n_exp)
+  cy = np.sign(np.sin(th)) * np.abs(np.sin(th)) ** (2.0 / n_exp)
+  ax, ay, hz = 0.0475, 0.029, 0.19
+  X = ax * r[:, None] * cx[None]
+  Y = ay * r[:, None] * cy[None]
+  Z = hz * (zs[:, None] - 0.5) * np.ones_like(X)
+  verts = np.stack([X, Y, Z], -1).reshape(-1, 3)
+  bottom = np.array([[0, 0, -hz / 2 - 0.0005]])
+  top = np.array([[0, 0, hz / 2 + 0.0005]])
+  verts = np.concatenate([verts, bottom, top], 0)
+  ib, it_ = n_z * n_theta, n_z * n_theta + 1
+  faces = []
+  for k in range(n_z - 1):
+    a = k * n_theta + np.arange(n_theta)
+    b = k * n_theta + (np.arange(n_theta) + 1) % n_theta
+    c = a + n_theta
+    d = b + n_theta
+    faces.append(np.stack([a, b, d], 1))
+    faces.append(np.stack([a, d, c], 1))
+  a = np.arange(n_theta)
+  b = (np.arange(n_theta) + 1) % n_theta
+  faces.append(np.stack([np.full(n_theta, ib), b, a], 1))
+  a2 = (n_z - 1) * n_theta + a
+  b2 = (n_z - 1) * n_theta + b
+  faces.append(np.stack([np.full(n_theta, it_), a2, b2], 1))
+  faces = np.concatenate(faces, 0)
+  # smooth seeded colour field + a higher-frequency "label" band
+  ph = rs.uniform(0, 2 * np.pi, size=(3, 4))
+  fr = rs.uniform(15, 60, size=(3, 4, 3))
+  col = np.zeros((len(verts), 3))
+  for c in range(3):
+    for k in range(4):
+      col[:, c] += np.sin(verts @ fr[c, k] + ph[c, k]) / 4.0
+  col = 0.5 + 0.45 * col
+  band = (np.abs(verts[:, 2]) < 0.035)
+  stripes = 0.5 + 0.5 * np.sign(np.sin(verts[:, 2] * 900.0 + np.arctan2(verts[:, 1], verts[:, 0]) * 6.0))
+  col[band] = 0.6 * col[band] + 0.4 * stripes[band, None] * np.array([0.9, 0.2, 0.1])
+  vc = np.concatenate([np.clip(col * 255, 0, 255).astype(np.uint8), np.full((len(verts), 1), 255, np.uint8)], 1)
+  mesh = SimpleMesh(verts, faces, vertex_colors=vc)
+  if textured:
+    tex = (rs.uniform(0, 1, size=(64, 64, 3)) * 255).astype(np.uint8)
+    tex = np.kron(tex, np.ones((8, 8, 1), np.uint8))        # 512x512 blocky seeded texture
+    ang = np.arctan2(verts[:, 1], verts[:, 0]) / (2 * np.pi) + 0.5
+    uv = np.stack([ang, (verts[:, 2] / hz) + 0.5], 1)
+    mesh.visual = TextureVisual(uv=uv, image=tex)
+  return mesh
+
+
+def random_rotation(rs):
+  q = rs.randn(4)
+  q /= np.linalg.norm(q)
+  w, x, y, z = q
+  return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def make_scene(render_fn, mesh_tensors, seed=0, H=480, W=640, K=YCB_K, t=(0.02, -0.03, 0.75)):
+  """One RGB-D frame: object at a seeded GT pose over a textured fronto-parallel background plane at
+  z = 1.2 m, depth noise N(0, 1 mm), 2 % dropout.  `render_fn(K,H,W,pose(1,4,4)) -> (color (H,W,3)
+  in [0,1], depth (H,W))` numpy arrays (oracle renderer on CPU, HIP renderer on the GPU box)."""
+  rs = np.random.RandomState(seed + 1000)
+  gt = np.eye(4)
+  gt[:3, :3] = random_rotation(rs)
+  gt[:3, 3] = t
+  color, depth = render_fn(K, H, W, gt[None].astype(np.float32))
+  color = np.asarray(color, dtype=np.float32).reshape(H, W, 3)
+  depth = np.asarray(depth, dtype=np.float32).reshape(H, W)
+  mask = depth > 0
+  vs, us = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+  bg = np.stack([0.5 + 0.3 * np.sin(us * 0.07) * np.cos(vs * 0.05),
+                 0.45 + 0.3 * np.sin(us * 0.031 + vs * 0.043),
+                 0.4 + 0.25 * np.cos(vs * 0.09 - us * 0.02)], -1)
+  rgb = np.where(mask[..., None], color, bg)
+  rgb = np.clip(rgb * 255.0 + rs.randn(H, W, 3) * 1.5, 0, 255).astype(np.uint8)
+  d = np.where(mask, depth, 1.2).astype(np.float32)
+  d = d + (rs.randn(H, W) * 0.001).astype(np.float32)
+  d[rs.uniform(size=(H, W)) < 0.02] = 0
+  return dict(K=np.array(K, dtype=np.float64), rgb=rgb, depth=d.astype(np.float32), mask=mask, gt_pose=gt.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded network parameters in the reference's state_dict layout
+# ----------------------------------------------------------------------------------------------
+def _conv(rs, sd, name, cout, cin, k, gain=1.0):
+  std = gain * math.sqrt(2.0 / (cin * k * k))
+  sd[f'{name}.weight'] = torch.from_numpy((rs.randn(cout, cin, k, k) * std).astype(np.float32))
+  sd[f'{name}.bias'] = torch.from_numpy((rs.randn(cout) * 0.02).astype(np.float32))
+
+
+def _bn(rs, sd, name, c):
+  sd[f'{name}.weight'] = torch.from_numpy(rs.uniform(0.8, 1.2, c).astype(np.float32))
+  sd[f'{name}.bias'] = torch.from_numpy((rs.randn(c) * 0.05).astype(np.float32))
+  sd[f'{name}.running_mean'] = torch.from_numpy((rs.randn(c) * 0.05).astype(np.float32))
+  sd[f'{name}.running_var'] = torch.from_numpy(rs.uniform(0.8, 1.2, c).astype(np.float32))
+  sd[f'{name}.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
+
+
+def _linear(rs, sd, name, cout, cin, gain=1.0):
+  bound = gain / math.sqrt(cin)
+  sd[f'{name}.weight'] = torch.from_numpy(rs.uniform(-bound, bound, (cout, cin)).astype(np.float32))
+  sd[f'{name}.bias'] = torch.from_numpy(rs.uniform(-bound, bound, cout).astype(np.float32))
+
+
+def _mha(rs, sd, name, d=512):
+  bound = math.sqrt(6.0 / (d + 3 * d))
+  sd[f'{name}.in_proj_weight'] = torch.from_numpy(rs.uniform(-bound, bound, (3 * d, d)).astype(np.float32))
+  sd[f'{name}.in_proj_bias'] = torch.from_numpy((rs.randn(3 * d) * 0.02).astype(np.float32))
+  _linear(rs, sd, f'{name}.out_proj', d, d)
+
+
+def _trunk(rs, sd, encA, encAB, c_in, use_bn):
+  def cbr(pre, cout, cin, k):
+    _conv(rs, sd, f'{pre}.net.0', cout, cin, k)
+    if use_bn:
+      _bn(rs, sd, f'{pre}.net.1', cout)
+
+  def res(pre, c):
+    _conv(rs, sd, f'{pre}.conv1', c, c, 3)
+    if use_bn: _bn(rs, sd, f'{pre}.bn1', c)
+    _conv(rs, sd, f'{pre}.conv2', c, c, 3, gain=0.5)
+    if use_bn: _bn(rs, sd, f'{pre}.bn2', c)
+  cbr(f'{encA}.0', 64, c_in, 7)
+  cbr(f'{encA}.1', 128, 64, 3)
+  res(f'{encA}.2', 128)
+  res(f'{encA}.3', 128)
+  res(f'{encAB}.0', 256)
+  res(f'{encAB}.1', 256)
+  cbr(f'{encAB}.2', 512, 256, 3)
+  res(f'{encAB}.3', 512)
+  res(f'{encAB}.4', 512)
+
+
+def positional_embedding(d_model=512, max_len=400):
+  """learning/models/network_modules.py:115-137 (buffer `pos_embed.pe`, shape (1,max_len,d))."""
+  pe = torch.zeros(max_len, d_model).float()
+  position = torch.arange(0, max_len).float().unsqueeze(1)
+  div_term = (torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model)).exp()[None]
+  pe[:, 0::2] = torch.sin(position * div_term)
+  pe[:, 1::2] = torch.cos(position * div_term)
+  return pe.unsqueeze(0)
+
+
+def make_refine_state_dict(seed=0, c_in=6, use_bn=True, rot_out_dim=3, head_gain=0.1):
+  """Keys = RefineNet.state_dict() (refine_network.py:27-70).  `head_gain` scales the two output
+  Linear(512,3) layers so that seeded-random refinement steps stay small (mm / ~1 deg)."""
+  rs = np.random.RandomState(seed)
+  sd = {}
+  _trunk(rs, sd, 'encodeA', 'encodeAB', c_in, use_bn)
+  sd['pos_embed.pe'] = positional_embedding()
+  for head, od in (('trans_head', 3), ('rot_head', rot_out_dim)):
+    _mha(rs, sd, f'{head}.0.self_attn')
+    _linear(rs, sd, f'{head}.0.linear1', 512, 512)
+    _linear(rs, sd, f'{head}.0.linear2', 512, 512)
+    for n in ('norm1', 'norm2'):
+      sd[f'{head}.0.{n}.weight'] = torch.from_numpy(rs.uniform(0.8, 1.2, 512).astype(np.float32))
+      sd[f'{head}.0.{n}.bias'] = torch.from_numpy((rs.randn(512) * 0.05).astype(np.float32))
+    _linear(rs, sd, f'{head}.1', od, 512, gain=head_gain)
+  return sd
+
+
+def make_score_state_dict(seed=1, c_in=6, use_bn=True):
+  """Keys = ScoreNetMultiPair.state_dict() (score_network.py:28-57)."""
+  rs = np.random.RandomState(seed)
+  sd = {}
+  _trunk(rs, sd, 'encoderA', 'encoderAB', c_in, use_bn)
+  _mha(rs, sd, 'att')
+  _mha(rs, sd, 'att_cross')
+  sd['pos_embed.pe'] = positional_embedding()
+  _linear(rs, sd, 'linear', 1, 512)
+  return sd

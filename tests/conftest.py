@@ -1,0 +1,18 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+if REPO not in sys.path:
+  sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+  config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+  import numpy as np
+  return np.load(os.path.join(REPO, 'tests', 'golden', 'reference_outputs.npz'))
