@@ -1,0 +1,232 @@
+"""ctypes binding of libfoundationpose_amd.so (C-ABI: include/foundationpose_amd.h).
+
+There is no CPU fallback: if the HIP library has not been built, importing an op raises with the
+build command.  torch is used only for device memory and the current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libfoundationpose_amd.so')
+_lib = None
+
+FP_NET_REFINE, FP_NET_SCORE = 0, 1
+
+
+class FpTensor(Structure):
+  _fields_ = [('name', c_char_p), ('data', c_void_p), ('ndim', c_int), ('shape', c_int64 * 4)]
+
+
+class FpRefineCfg(Structure):
+  _fields_ = [('crop_ratio', c_double), ('normalize_xyz', c_int), ('trans_rep_tanh', c_int),
+              ('trans_normalizer', c_float * 3), ('rot_normalizer', c_float)]
+
+
+class FoundationPoseAmdError(RuntimeError):
+  pass
+
+
+_PROTOS = {
+  'fp_last_error': (c_char_p, []),
+  'fp_version': (c_int, []),
+  'fp_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
+  'fp_ctx_destroy': (c_int, [c_void_p]),
+  'fp_ctx_reserve': (c_int, [c_void_p, c_int]),
+  'fp_mesh_create': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+  'fp_mesh_destroy': (c_int, [c_void_p]),
+  'fp_crop_window_tf': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_render': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'fp_render_net': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_float, c_void_p, c_void_p]),
+  'fp_crop_observed': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p, c_void_p]),
+  'fp_erode_depth': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
+  'fp_bilateral_filter_depth': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
+  'fp_depth2xyzmap': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
+  'fp_net_create': (c_int, [c_void_p, c_int, POINTER(FpTensor), c_int, c_int, POINTER(c_void_p)]),
+  'fp_net_destroy': (c_int, [c_void_p]),
+  'fp_net_rot_dim': (c_int, [c_void_p]),
+  'fp_refine_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_score_features': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+  'fp_score_tail': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_pose_update': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p]),
+  'fp_refine_predict': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, POINTER(FpRefineCfg), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_score_predict_features': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, c_double, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+  'fp_conv2d_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+  'fp_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+  'fp_cluster_poses': (c_int, [c_float, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+  'fp_prof_enable': (c_int, [c_void_p, c_int]),
+  'fp_prof_read': (c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
+  'fp_prof_reset': (c_int, [c_void_p]),
+}
+
+
+def exported_symbols():
+  """Names declared in include/foundationpose_amd.h (kept in step by tests/test_abi.py)."""
+  return sorted(_PROTOS)
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise FoundationPoseAmdError(
+        f'{LIB_PATH} is missing: build the HIP library first (python -c "import __graft_entry__ as g; g.build()" '
+        f'or make -C foundationpose_amd/csrc).  foundationpose_amd has no CPU fallback.')
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+      fn = getattr(L, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = L
+  return _lib
+
+
+def check(rc):
+  if rc != 0:
+    msg = lib().fp_last_error()
+    raise FoundationPoseAmdError(f'libfoundationpose_amd error {rc}: {msg.decode() if msg else "?"}')
+
+
+def ptr(t):
+  """Device (or host) address of a contiguous torch tensor / numpy array; None -> NULL."""
+  if t is None:
+    return None
+  if torch.is_tensor(t):
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    return c_void_p(t.data_ptr())
+  assert t.flags['C_CONTIGUOUS']
+  return c_void_p(t.ctypes.data)
+
+
+def stream_ptr(device=None):
+  return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def k_ptr(K):
+  """3x3 intrinsics as a float64 host array (kept alive by the caller)."""
+  if torch.is_tensor(K):
+    K = K.detach().cpu().numpy()
+  Kd = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3))
+  return Kd, c_void_p(Kd.ctypes.data)
+
+
+class Context:
+  """Per-device fp_ctx (workspace arena + profiling).  The opaque handle the reference calls
+  `glctx` (dr.RasterizeCudaContext, src/estimater.py:102,168; main.py:42)."""
+  _by_device = {}
+
+  def __init__(self, device_index):
+    self.device_index = device_index
+    h = c_void_p()
+    check(lib().fp_ctx_create(device_index, byref(h)))
+    self.handle = h
+
+  @classmethod
+  def get(cls, device=None):
+    if device is None:
+      idx = torch.cuda.current_device()
+    else:
+      d = torch.device(device)
+      idx = d.index if d.index is not None else torch.cuda.current_device()
+    if idx not in cls._by_device:
+      if not torch.cuda.is_available():
+        raise FoundationPoseAmdError('no HIP device visible: foundationpose_amd needs an MI355X (no CPU fallback)')
+      cls._by_device[idx] = Context(idx)
+    return cls._by_device[idx]
+
+  def reserve(self, max_hyp):
+    check(lib().fp_ctx_reserve(self.handle, int(max_hyp)))
+
+  def prof_enable(self, on=True):
+    check(lib().fp_prof_enable(self.handle, 1 if on else 0))
+
+  def prof_reset(self):
+    check(lib().fp_prof_reset(self.handle))
+
+  def prof_read(self, cls_name):
+    ms, n, fl = c_double(), c_int64(), c_double()
+    check(lib().fp_prof_read(self.handle, cls_name.encode(), byref(ms), byref(n), byref(fl)))
+    return dict(total_ms=ms.value, launches=n.value, flops=fl.value)
+
+
+class DeviceMesh:
+  """fp_mesh built from a reference-layout mesh_tensors dict (src/Utils.py:104-130)."""
+
+  def __init__(self, ctx, mesh_tensors):
+    f32 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))
+    i32 = lambda t: np.ascontiguousarray(t.detach().cpu().numpy().astype(np.int32))
+    pos, faces, vn = f32(mesh_tensors['pos']), i32(mesh_tensors['faces']), f32(mesh_tensors['vnormals'])
+    h = c_void_p()
+    if 'tex' in mesh_tensors:
+      tex = f32(mesh_tensors['tex']).reshape(mesh_tensors['tex'].shape[-3], mesh_tensors['tex'].shape[-2], 3)
+      uv, uvi = f32(mesh_tensors['uv']), i32(mesh_tensors['uv_idx'])
+      check(lib().fp_mesh_create(ctx.handle, ptr(pos), len(pos), ptr(faces), len(faces), ptr(vn), None, ptr(uv), len(uv), ptr(uvi),
+                                 ptr(tex), tex.shape[0], tex.shape[1], byref(h)))
+    else:
+      vc = f32(mesh_tensors['vertex_color'])
+      check(lib().fp_mesh_create(ctx.handle, ptr(pos), len(pos), ptr(faces), len(faces), ptr(vn), ptr(vc), None, 0, None, None, 0, 0,
+                                 byref(h)))
+    self.handle = h
+    self.ctx = ctx
+
+  def __del__(self):
+    try:
+      if self.handle:
+        lib().fp_mesh_destroy(self.handle)
+        self.handle = None
+    except Exception:
+      pass
+
+
+_mesh_cache = {}
+
+
+def device_mesh(ctx, mesh_tensors):
+  """Cache the uploaded mesh per (device, pos storage)."""
+  key = (ctx.device_index, mesh_tensors['pos'].data_ptr(), mesh_tensors['faces'].data_ptr(), tuple(mesh_tensors['pos'].shape))
+  m = _mesh_cache.get(key)
+  if m is None:
+    if len(_mesh_cache) > 16:
+      _mesh_cache.clear()
+    m = DeviceMesh(ctx, mesh_tensors)
+    _mesh_cache[key] = m
+  return m
+
+
+class DeviceNet:
+  """fp_net built from a reference-layout state_dict (torch tensors)."""
+
+  def __init__(self, ctx, kind, state_dict, use_bn=True):
+    keep = []
+    arr = (FpTensor * len(state_dict))()
+    n = 0
+    for k, v in state_dict.items():
+      if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+        continue
+      a = np.ascontiguousarray(v.detach().cpu().float().numpy())
+      keep.append(a)
+      kb = k.encode()
+      keep.append(kb)
+      arr[n].name = kb
+      arr[n].data = a.ctypes.data
+      arr[n].ndim = a.ndim
+      for i in range(min(a.ndim, 4)):
+        arr[n].shape[i] = a.shape[i]
+      n += 1
+    h = c_void_p()
+    check(lib().fp_net_create(ctx.handle, kind, arr, n, 1 if use_bn else 0, byref(h)))
+    self.handle = h
+    self.ctx = ctx
+    self.kind = kind
+    self.rot_dim = lib().fp_net_rot_dim(h) if kind == FP_NET_REFINE else 0
+
+  def __del__(self):
+    try:
+      if self.handle:
+        lib().fp_net_destroy(self.handle)
+        self.handle = None
+    except Exception:
+      pass

@@ -1,0 +1,454 @@
+// extern "C" entry points of libfoundationpose_amd (see include/foundationpose_amd.h).
+#include "common.h"
+
+#include <cmath>
+#include <cstdarg>
+
+static thread_local char g_err[1024] = "";
+
+void fp_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *fp_last_error(void) { return g_err; }
+extern "C" int fp_version(void) { return 100; }
+
+// ---- context / arena ---------------------------------------------------------------------------
+size_t fp_arena_bytes_for(int n_hyp) {
+  // per hypothesis: net input 0.82 MB, encoder activations ~7.8 MB, tokens + attention ~4.1 MB (see DESIGN.md "HBM layout")
+  return (size_t)n_hyp * (size_t)(14u << 20) + ((size_t)64 << 20);
+}
+
+size_t fp_arena_inner_bytes(int n_hyp) {
+  // exact sum of the forward's buffers is 11,485,184 B per hypothesis (DESIGN.md "HBM layout")
+  return (size_t)n_hyp * (size_t)(12u << 20) + ((size_t)8 << 20);
+}
+
+int fp_arena_ensure(fp_ctx *ctx, size_t bytes) {
+  Arena &a = ctx->arena;
+  if (a.cap - a.off >= bytes && a.base) return FP_OK;
+  if (a.off != 0) {
+    fp_set_error("arena too small for a nested request of %zu bytes (cap %zu, used %zu); call fp_ctx_reserve first", bytes, a.cap, a.off);
+    return FP_ENOMEM;
+  }
+  FP_CHECK_HIP(hipSetDevice(ctx->device));
+  if (a.base) {
+    FP_CHECK_HIP(hipDeviceSynchronize());
+    FP_CHECK_HIP(hipFree(a.base));
+    a.base = nullptr;
+    a.cap = 0;
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    fp_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return FP_ENOMEM;
+  }
+  a.base = (char *)p;
+  a.cap = bytes;
+  a.off = 0;
+  return FP_OK;
+}
+
+extern "C" int fp_ctx_create(int device, fp_ctx **out) {
+  FP_REQUIRE(out, "fp_ctx_create: null out");
+  int n = 0;
+  FP_CHECK_HIP(hipGetDeviceCount(&n));
+  FP_REQUIRE(device >= 0 && device < n, "fp_ctx_create: device %d out of range (%d visible)", device, n);
+  FP_CHECK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  FP_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  fp_ctx *c = new fp_ctx;
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount;
+  *out = c;
+  return FP_OK;
+}
+
+extern "C" int fp_ctx_destroy(fp_ctx *ctx) {
+  if (!ctx) return FP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto &e : ctx->pending) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+  delete ctx;
+  return FP_OK;
+}
+
+extern "C" int fp_ctx_reserve(fp_ctx *ctx, int max_hyp) {
+  FP_REQUIRE(ctx && max_hyp >= 1, "fp_ctx_reserve: bad argument");
+  FP_REQUIRE(ctx->arena.off == 0, "fp_ctx_reserve: arena in use");
+  size_t need = fp_arena_bytes_for(max_hyp);
+  if (ctx->arena.cap >= need) return FP_OK;
+  ctx->arena.off = 0;
+  Arena &a = ctx->arena;
+  if (a.base) {
+    FP_CHECK_HIP(hipDeviceSynchronize());
+    FP_CHECK_HIP(hipFree(a.base));
+    a.base = nullptr;
+    a.cap = 0;
+  }
+  FP_TRY(fp_arena_ensure(ctx, need));
+  ctx->reserved_hyp = max_hyp;
+  return FP_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+extern "C" int fp_prof_enable(fp_ctx *ctx, int on) {
+  FP_REQUIRE(ctx, "fp_prof_enable: null ctx");
+  ctx->prof = on != 0;
+  return FP_OK;
+}
+
+static int prof_drain(fp_ctx *ctx) {
+  for (auto &e : ctx->pending) {
+    FP_CHECK_HIP(hipEventSynchronize(e.b));
+    float ms = 0.f;
+    FP_CHECK_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+    ProfEntry &p = ctx->prof_tab[e.cls];
+    p.total_ms += ms;
+    p.flops += e.flops;
+    p.launches += 1;
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  ctx->pending.clear();
+  return FP_OK;
+}
+
+extern "C" int fp_prof_read(fp_ctx *ctx, const char *cls, double *total_ms, int64_t *launches, double *flops) {
+  FP_REQUIRE(ctx && cls, "fp_prof_read: null argument");
+  FP_TRY(prof_drain(ctx));
+  auto it = ctx->prof_tab.find(cls);
+  ProfEntry e = (it == ctx->prof_tab.end()) ? ProfEntry() : it->second;
+  if (total_ms) *total_ms = e.total_ms;
+  if (launches) *launches = e.launches;
+  if (flops) *flops = e.flops;
+  return FP_OK;
+}
+
+extern "C" int fp_prof_reset(fp_ctx *ctx) {
+  FP_REQUIRE(ctx, "fp_prof_reset: null ctx");
+  FP_TRY(prof_drain(ctx));
+  ctx->prof_tab.clear();
+  return FP_OK;
+}
+
+// ---- mesh --------------------------------------------------------------------------------------
+template <typename T>
+static int up(fp_mesh *m, const T *h, size_t n, const T **d) {
+  void *p = nullptr;
+  FP_CHECK_HIP(hipMalloc(&p, n * sizeof(T)));
+  m->allocs.push_back(p);
+  FP_CHECK_HIP(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice));
+  *d = (const T *)p;
+  return FP_OK;
+}
+
+extern "C" int fp_mesh_create(fp_ctx *ctx, const float *h_pos, int V, const int32_t *h_faces, int F, const float *h_vnormals,
+                              const float *h_vertex_color, const float *h_uv, int n_uv, const int32_t *h_uv_idx, const float *h_tex,
+                              int texH, int texW, fp_mesh **out) {
+  FP_REQUIRE(ctx && h_pos && h_faces && h_vnormals && out, "fp_mesh_create: null argument");
+  FP_REQUIRE(V > 0 && F > 0, "fp_mesh_create: empty mesh (V=%d F=%d)", V, F);
+  FP_REQUIRE(h_vertex_color || (h_uv && h_uv_idx && h_tex && texH > 0 && texW > 0 && n_uv > 0),
+             "fp_mesh_create: need vertex colours or (uv, uv_idx, tex)");
+  for (int i = 0; i < F * 3; ++i) FP_REQUIRE(h_faces[i] >= 0 && h_faces[i] < V, "fp_mesh_create: face index %d out of range", h_faces[i]);
+  const bool textured = (h_tex != nullptr && h_vertex_color == nullptr);
+  if (textured)
+    for (int i = 0; i < F * 3; ++i) FP_REQUIRE(h_uv_idx[i] >= 0 && h_uv_idx[i] < n_uv, "fp_mesh_create: uv index out of range");
+  FP_CHECK_HIP(hipSetDevice(ctx->device));
+  fp_mesh *m = new fp_mesh;
+  memset(&m->d, 0, sizeof(MeshDev));
+  m->d.V = V;
+  m->d.F = F;
+  int rc = FP_OK;
+  auto run = [&]() -> int {
+    FP_TRY(up(m, h_pos, (size_t)V * 3, &m->d.pos));
+    FP_TRY(up(m, h_faces, (size_t)F * 3, &m->d.faces));
+    FP_TRY(up(m, h_vnormals, (size_t)V * 3, &m->d.vnormals));
+    if (textured) {
+      FP_TRY(up(m, h_uv, (size_t)n_uv * 2, &m->d.uv));
+      FP_TRY(up(m, h_uv_idx, (size_t)F * 3, &m->d.uv_idx));
+      FP_TRY(up(m, h_tex, (size_t)texH * texW * 3, &m->d.tex));
+      m->d.texH = texH;
+      m->d.texW = texW;
+    } else {
+      FP_TRY(up(m, h_vertex_color, (size_t)V * 3, &m->d.vcolor));
+    }
+    return FP_OK;
+  };
+  rc = run();
+  if (rc != FP_OK) {
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return FP_OK;
+}
+
+extern "C" int fp_mesh_destroy(fp_mesh *m) {
+  if (!m) return FP_OK;
+  for (void *p : m->allocs) (void)hipFree(p);
+  delete m;
+  return FP_OK;
+}
+
+// ---- render / crops ------------------------------------------------------------------------------
+extern "C" int fp_crop_window_tf(fp_ctx *ctx, const float *d_poses, int N, const double *K, double crop_ratio, double mesh_diameter,
+                                 int out_w, int out_h, float *d_tf, float *d_bbox2d, void *stream) {
+  FP_REQUIRE(ctx && d_poses && K && d_tf, "fp_crop_window_tf: null argument");
+  FP_REQUIRE(N >= 0 && out_w > 0 && out_h > 0 && mesh_diameter > 0 && crop_ratio > 0, "fp_crop_window_tf: bad argument");
+  return launch_crop_window_tf(d_poses, N, K, crop_ratio, mesh_diameter, out_w, out_h, d_tf, d_bbox2d, (hipStream_t)stream);
+}
+
+static int fill_render(RenderArgs &a, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+                       const float *d_bbox2d, int out_h, int out_w) {
+  FP_REQUIRE(mesh && d_poses && K, "render: null argument");
+  FP_REQUIRE(N >= 0 && H > 0 && W > 0 && out_h > 0 && out_w > 0, "render: bad shape");
+  memset(&a, 0, sizeof(a));
+  a.mesh = mesh->d;
+  a.poses = d_poses;
+  a.bbox2d = d_bbox2d;
+  for (int i = 0; i < 9; ++i) a.K[i] = K[i];
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.Ho = out_h;
+  a.Wo = out_w;
+  return FP_OK;
+}
+
+extern "C" int fp_render(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+                         const float *d_bbox2d, int out_h, int out_w, int use_light, float w_ambient, float w_diffuse, float *d_color,
+                         float *d_depth, float *d_normal, float *d_xyz, void *stream) {
+  FP_REQUIRE(ctx, "fp_render: null ctx");
+  RenderArgs a;
+  FP_TRY(fill_render(a, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w));
+  a.use_light = use_light;
+  a.w_ambient = w_ambient;
+  a.w_diffuse = w_diffuse;
+  a.color = d_color;
+  a.depth = d_depth;
+  a.normal = d_normal;
+  a.xyz = d_xyz;
+  return launch_render(ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int fp_render_net(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+                             const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
+                             void *d_net_out, void *stream) {
+  FP_REQUIRE(ctx && d_net_out, "fp_render_net: null argument");
+  RenderArgs a;
+  FP_TRY(fill_render(a, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w));
+  a.use_light = 1;  // make_crop_data_batch renders with use_light=True (predict_pose_refine.py:49)
+  a.w_ambient = 0.8f;
+  a.w_diffuse = 0.5f;
+  a.net_out = (f16 *)d_net_out;
+  a.mesh_diameter = (float)mesh_diameter;
+  a.invalid_thres = invalid_thres;
+  a.normalize_xyz = normalize_xyz;
+  return launch_render(ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int fp_crop_observed(fp_ctx *ctx, const float *d_rgb, const float *d_geom, int H, int W, const double *K, const float *d_tf,
+                                const float *d_poses, int N, int out_h, int out_w, int mode, double mesh_diameter, int normalize_xyz,
+                                int out_fmt, void *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_rgb && d_geom && K && d_tf && d_poses && d_out, "fp_crop_observed: null argument");
+  FP_REQUIRE(out_fmt == 0 || out_fmt == 1, "fp_crop_observed: out_fmt must be 0 or 1");
+  CropArgs a;
+  a.rgb = d_rgb;
+  a.geom = d_geom;
+  a.tf = d_tf;
+  a.poses = d_poses;
+  for (int i = 0; i < 9; ++i) a.K[i] = K[i];
+  a.H = H;
+  a.W = W;
+  a.N = N;
+  a.Ho = out_h;
+  a.Wo = out_w;
+  a.mode = mode;
+  a.normalize_xyz = normalize_xyz;
+  a.out_fmt = out_fmt;
+  a.mesh_diameter = (float)mesh_diameter;
+  a.out = d_out;
+  return launch_crop_observed(a, (hipStream_t)stream);
+}
+
+extern "C" int fp_erode_depth(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
+                              float zfar, float *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_depth && d_out && H > 0 && W > 0 && radius >= 0, "fp_erode_depth: bad argument");
+  return launch_erode(d_depth, H, W, radius, depth_diff_thres, ratio_thres, zfar, d_out, (hipStream_t)stream);
+}
+extern "C" int fp_bilateral_filter_depth(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float zfar, float sigmaD,
+                                         float sigmaR, float *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_depth && d_out && H > 0 && W > 0 && radius >= 0, "fp_bilateral_filter_depth: bad argument");
+  return launch_bilateral(d_depth, H, W, radius, zfar, sigmaD, sigmaR, d_out, (hipStream_t)stream);
+}
+extern "C" int fp_depth2xyzmap(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float zfar, float *d_xyz, void *stream) {
+  FP_REQUIRE(ctx && d_depth && d_xyz && K && H > 0 && W > 0, "fp_depth2xyzmap: bad argument");
+  return launch_depth2xyz(d_depth, H, W, K, zfar, d_xyz, (hipStream_t)stream);
+}
+
+extern "C" int fp_pose_update(fp_ctx *ctx, const float *d_poseA, const float *d_trans, const float *d_rot, int N, int rot_dim,
+                              int trans_rep_tanh, const float *tn, float rot_normalizer, float trans_scale, float *d_pose_out,
+                              void *stream) {
+  FP_REQUIRE(ctx && d_poseA && d_trans && d_rot && d_pose_out, "fp_pose_update: null argument");
+  float t0 = tn ? tn[0] : 1.f, t1 = tn ? tn[1] : 1.f, t2 = tn ? tn[2] : 1.f;
+  return launch_pose_update(d_poseA, d_trans, d_rot, N, rot_dim, trans_rep_tanh, t0, t1, t2, rot_normalizer, trans_scale, d_pose_out,
+                            (hipStream_t)stream);
+}
+
+// ---- composed loops --------------------------------------------------------------------------------
+#define TAKE(ptr, type, count)                                                             \
+  type *ptr = (type *)ctx->arena.take((size_t)(count) * sizeof(type));                     \
+  if (!ptr) {                                                                              \
+    fp_set_error("arena exhausted (%s); call fp_ctx_reserve with a larger max_hyp", #ptr); \
+    return FP_ENOMEM;                                                                      \
+  }
+
+extern "C" int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_xyz_map,
+                                 int H, int W, const double *K, double mesh_diameter, const fp_refine_cfg *cfg, float *d_poses, int N,
+                                 int iteration, float *d_trans, float *d_rot, void *stream) {
+  FP_REQUIRE(ctx && net && mesh && d_rgb && d_xyz_map && K && cfg && d_poses, "fp_refine_predict: null argument");
+  FP_REQUIRE(N >= 0 && iteration >= 0, "fp_refine_predict: bad N/iteration");
+  if (N == 0 || iteration == 0) return FP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int rot_dim = fp_net_rot_dim(net);
+  FP_TRY(fp_arena_ensure(ctx, fp_arena_bytes_for(N)));
+  const size_t mark = ctx->arena.off;
+  auto body = [&]() -> int {
+    TAKE(tf, float, (size_t)N * 9);
+    TAKE(bbox, float, (size_t)N * 4);
+    TAKE(trans, float, (size_t)N * 3);
+    TAKE(rot, float, (size_t)N * 6);
+    TAKE(pose_tmp, float, (size_t)N * 16);
+    TAKE(net_in, f16, (size_t)2 * N * 160 * 160 * 8);
+    float *tr = d_trans ? d_trans : trans, *ro = d_rot ? d_rot : rot;
+    const float trans_scale = cfg->normalize_xyz ? (float)(mesh_diameter / 2) : 1.f;
+    for (int it = 0; it < iteration; ++it) {
+      FP_TRY(launch_crop_window_tf(d_poses, N, K, cfg->crop_ratio, mesh_diameter, 160, 160, tf, bbox, s));
+      FP_TRY(fp_render_net(ctx, mesh, d_poses, N, K, H, W, bbox, 160, 160, mesh_diameter, cfg->normalize_xyz, 0.001f, net_in, s));
+      FP_TRY(fp_crop_observed(ctx, d_rgb, d_xyz_map, H, W, K, tf, d_poses, N, 160, 160, 0, mesh_diameter, cfg->normalize_xyz, 1,
+                              net_in + (size_t)N * 160 * 160 * 8, s));
+      FP_TRY(fp_refine_forward(ctx, net, net_in, N, tr, ro, s));
+      FP_TRY(launch_pose_update(d_poses, tr, ro, N, rot_dim, cfg->trans_rep_tanh, cfg->trans_normalizer[0], cfg->trans_normalizer[1],
+                                cfg->trans_normalizer[2], cfg->rot_normalizer, trans_scale, pose_tmp, s));
+      FP_CHECK_HIP(hipMemcpyAsync(d_poses, pose_tmp, (size_t)N * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return FP_OK;
+  };
+  int rc = body();
+  ctx->arena.off = mark;
+  return rc;
+}
+
+extern "C" int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_depth,
+                                         int H, int W, const double *K, double mesh_diameter, double crop_ratio, int normalize_xyz,
+                                         const float *d_poses, int N, float *d_feats, void *stream) {
+  FP_REQUIRE(ctx && net && mesh && d_rgb && d_depth && K && d_poses && d_feats, "fp_score_predict_features: null argument");
+  FP_REQUIRE(N >= 0, "fp_score_predict_features: N<0");
+  if (N == 0) return FP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  FP_TRY(fp_arena_ensure(ctx, fp_arena_bytes_for(N)));
+  const size_t mark = ctx->arena.off;
+  auto body = [&]() -> int {
+    TAKE(tf, float, (size_t)N * 9);
+    TAKE(bbox, float, (size_t)N * 4);
+    TAKE(net_in, f16, (size_t)2 * N * 160 * 160 * 8);
+    FP_TRY(launch_crop_window_tf(d_poses, N, K, crop_ratio, mesh_diameter, 160, 160, tf, bbox, s));
+    FP_TRY(fp_render_net(ctx, mesh, d_poses, N, K, H, W, bbox, 160, 160, mesh_diameter, normalize_xyz, 0.1f, net_in, s));
+    FP_TRY(fp_crop_observed(ctx, d_rgb, d_depth, H, W, K, tf, d_poses, N, 160, 160, 1, mesh_diameter, normalize_xyz, 1,
+                            net_in + (size_t)N * 160 * 160 * 8, s));
+    FP_TRY(fp_score_features(ctx, net, net_in, N, d_feats, s));
+    return FP_OK;
+  };
+  int rc = body();
+  ctx->arena.off = mark;
+  return rc;
+}
+
+// ---- building blocks ---------------------------------------------------------------------------------
+extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin, const void *d_w_packed, const float *d_bias,
+                             int Cout, int KH, int KW, int stride, int pad, const void *d_res, int relu, void *d_out, int out_f32,
+                             void *stream) {
+  FP_REQUIRE(ctx && d_in && d_w_packed && d_bias && d_out, "fp_conv2d_f16: null argument");
+  FP_REQUIRE(stride >= 1 && pad >= 0 && Nimg >= 0, "fp_conv2d_f16: bad stride/pad/N");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = (const f16 *)d_in;
+  a.w = (const f16 *)d_w_packed;
+  a.bias = d_bias;
+  a.res = (const f16 *)d_res;
+  a.out = d_out;
+  a.Nimg = Nimg;
+  a.H = H;
+  a.W = W;
+  a.Cin = Cin;
+  a.KH = KH;
+  a.KW = KW;
+  a.stride = stride;
+  a.pad = pad;
+  a.Ho = (H + 2 * pad - KH) / stride + 1;
+  a.Wo = (W + 2 * pad - KW) / stride + 1;
+  a.Cout = Cout;
+  a.Kpad = (KH * KW * Cin + 31) / 32 * 32;
+  a.M = Nimg * a.Ho * a.Wo;
+  a.relu = relu;
+  a.out_mode = out_f32 ? 1 : 0;
+  a.out_ld = Cout;
+  a.split_m = 0x7fffffff;
+  a.post_period = 1;
+  a.tokens = 400;
+  return launch_conv(ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int fp_attention_f16(fp_ctx *ctx, const void *d_qk, const void *d_vt, int B, int T, void *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_qk && d_vt && d_out, "fp_attention_f16: null argument");
+  return launch_attention(ctx, (const f16 *)d_qk, (const f16 *)d_vt, B, T, (f16 *)d_out, (hipStream_t)stream);
+}
+
+// ---- host: mycpp.cluster_poses ------------------------------------------------------------------------
+extern "C" int fp_cluster_poses(float angle_diff_deg, float dist_diff_m, const float *in, int n_in, const float *sym, int n_sym,
+                                float *out) {
+  FP_REQUIRE(in && sym && out && n_in >= 1 && n_sym >= 1, "fp_cluster_poses: bad argument");
+  const float radian_thres = angle_diff_deg / 180.0f * (float)M_PI;
+  int n_out = 0;
+  auto keep = [&](const float *p) {
+    memcpy(out + (size_t)n_out * 16, p, 16 * sizeof(float));
+    ++n_out;
+  };
+  keep(in);
+  for (int i = 1; i < n_in; ++i) {
+    const float *cur = in + (size_t)i * 16;
+    bool isnew = true;
+    for (int c = 0; c < n_out && isnew; ++c) {
+      const float *cl = out + (size_t)c * 16;
+      float dx = cl[3] - cur[3], dy = cl[7] - cur[7], dz = cl[11] - cur[11];
+      if (std::sqrt(dx * dx + dy * dy + dz * dz) >= dist_diff_m) continue;
+      for (int k = 0; k < n_sym; ++k) {
+        const float *tf = sym + (size_t)k * 16;
+        float R[9];  // rotation block of cur @ tf
+        for (int r = 0; r < 3; ++r)
+          for (int cc = 0; cc < 3; ++cc) R[r * 3 + cc] = cur[r * 4] * tf[cc] + cur[r * 4 + 1] * tf[4 + cc] + cur[r * 4 + 2] * tf[8 + cc] + cur[r * 4 + 3] * tf[12 + cc];
+        float tr = 0.f;  // trace(R * cl_R^T)
+        for (int r = 0; r < 3; ++r)
+          for (int cc = 0; cc < 3; ++cc) tr += R[r * 3 + cc] * cl[r * 4 + cc];
+        float cs = (tr - 1.f) / 2.0f;
+        cs = std::fmax(std::fmin(cs, 1.0f), -1.0f);
+        if (std::acos(cs) < radian_thres) {
+          isnew = false;
+          break;
+        }
+      }
+    }
+    if (isnew) keep(cur);
+  }
+  return n_out;
+}

@@ -1,0 +1,167 @@
+// Shared host-side plumbing for libfoundationpose_amd (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/foundationpose_amd.h"
+
+typedef _Float16 f16;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+void fp_set_error(const char *fmt, ...);
+
+#define FP_CHECK_HIP(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      fp_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));     \
+      return FP_EHIP;                                                                        \
+    }                                                                                        \
+  } while (0)
+
+#define FP_REQUIRE(cond, ...)                                                                \
+  do {                                                                                       \
+    if (!(cond)) {                                                                           \
+      fp_set_error(__VA_ARGS__);                                                             \
+      return FP_EINVAL;                                                                      \
+    }                                                                                        \
+  } while (0)
+
+#define FP_TRY(expr)                 \
+  do {                               \
+    int _rc = (expr);                \
+    if (_rc != FP_OK) return _rc;    \
+  } while (0)
+
+struct MeshDev {
+  const float *pos, *vnormals, *vcolor, *uv, *tex;
+  const int32_t *faces, *uv_idx;
+  int V, F, texH, texW;
+};
+
+struct fp_mesh {
+  MeshDev d;
+  std::vector<void *> allocs;
+};
+
+struct ProfEntry {
+  double total_ms = 0, flops = 0;
+  int64_t launches = 0;
+};
+
+struct PendingEvent {
+  hipEvent_t a, b;
+  std::string cls;
+  double flops;
+};
+
+// Bump arena over one hipMalloc; reset at the start of every forward.
+struct Arena {
+  char *base = nullptr;
+  size_t cap = 0, off = 0;
+  void *take(size_t bytes) {
+    size_t o = (off + 255) & ~(size_t)255;
+    if (o + bytes > cap) return nullptr;
+    off = o + bytes;
+    return base + o;
+  }
+};
+
+struct fp_ctx {
+  int device = 0;
+  Arena arena;
+  int reserved_hyp = 0;
+  bool prof = false;
+  std::map<std::string, ProfEntry> prof_tab;
+  std::vector<PendingEvent> pending;
+  int num_cu = 256;
+};
+
+int fp_arena_ensure(fp_ctx *ctx, size_t bytes);
+size_t fp_arena_bytes_for(int n_hyp);     // whole refine/score pass (outer buffers + network)
+size_t fp_arena_inner_bytes(int n_hyp);   // network forward only
+
+// profiling hooks (events on the launch stream)
+struct ProfScope {
+  fp_ctx *ctx;
+  hipStream_t s;
+  PendingEvent ev;
+  bool on;
+  ProfScope(fp_ctx *c, hipStream_t st, const char *cls, double flops) : ctx(c), s(st), on(c && c->prof) {
+    if (on) {
+      (void)hipEventCreate(&ev.a);
+      (void)hipEventCreate(&ev.b);
+      ev.cls = cls;
+      ev.flops = flops;
+      (void)hipEventRecord(ev.a, s);
+    }
+  }
+  ~ProfScope() {
+    if (on) {
+      (void)hipEventRecord(ev.b, s);
+      ctx->pending.push_back(ev);
+    }
+  }
+};
+
+// ---- kernel launchers implemented in the .hip files ----
+struct ConvArgs {
+  const f16 *in;
+  const f16 *w;
+  const float *bias;
+  const f16 *res;
+  const float *post_add;
+  void *out;
+  int Nimg, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, Kpad, M;
+  int relu, out_mode;  // 0 fp16 NHWC, 1 fp32 NHWC, 2 fp16 V-transposed [b][4][128][416]
+  int out_ld, split_m, coff_hi, post_period, tokens;
+};
+int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
+
+int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s);
+int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
+int launch_ln_mean_head(const float *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
+                        int out_dim, float *out, hipStream_t s);
+int launch_token_mean(const f16 *x, int Bn, int T, float *out, hipStream_t s);
+int launch_small_linear(const float *x, const float *w, const float *b, int M, int K, int N, float *out, hipStream_t s);
+int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s);
+int launch_argmax(const float *logits, int groups, int L, int32_t *out, hipStream_t s);
+int launch_pose_update(const float *poseA, const float *trans, const float *rot, int N, int rot_dim, int trans_tanh,
+                       float tn0, float tn1, float tn2, float rot_normalizer, float trans_scale, float *out, hipStream_t s);
+
+struct RenderArgs {
+  MeshDev mesh;
+  const float *poses, *bbox2d;
+  double K[9];
+  int N, H, W, Ho, Wo;
+  int use_light;
+  float w_ambient, w_diffuse;
+  float *color, *depth, *normal, *xyz;  // mode 0
+  f16 *net_out;                         // mode 1
+  float mesh_diameter, invalid_thres;
+  int normalize_xyz;
+};
+int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s);
+int launch_crop_window_tf(const float *poses, int N, const double *K, double crop_ratio, double diameter, int ow, int oh, float *tf,
+                          float *bbox, hipStream_t s);
+
+struct CropArgs {
+  const float *rgb, *geom, *tf, *poses;
+  double K[9];
+  int H, W, N, Ho, Wo, mode, normalize_xyz, out_fmt;
+  float mesh_diameter;
+  void *out;
+};
+int launch_crop_observed(const CropArgs &a, hipStream_t s);
+
+int launch_erode(const float *d, int H, int W, int radius, float diff_thres, float ratio_thres, float zfar, float *out, hipStream_t s);
+int launch_bilateral(const float *d, int H, int W, int radius, float zfar, float sigmaD, float sigmaR, float *out, hipStream_t s);
+int launch_depth2xyz(const float *d, int H, int W, const double *K, float zfar, float *xyz, hipStream_t s);

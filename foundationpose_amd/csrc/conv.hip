@@ -1,0 +1,213 @@
+// fp16 NHWC implicit-GEMM convolution / linear layer on MFMA (gfx950).
+//
+// Replaces the cuDNN convolutions + BN + ReLU + residual adds of learning/models/network_modules.py:37-111
+// (BN folded into weights/bias at load) and, with KH=KW=1, every nn.Linear of the transformer heads.
+//
+//   out[m][co] = act( sum_{tap,ci} in[pix(m)+off(tap)][ci] * w[co][tap*Cin+ci] + bias[co] (+ res[m][co]) ) (+ post_add)
+//
+// GEMM view: M_gemm = Cout (weights are the MFMA A operand), N_gemm = pixels (activations are the B
+// operand, gathered per row straight from the NHWC tensor - no im2col buffer), K = KH*KW*Cin.
+// With this orientation a lane of the 32x32 accumulator owns ONE pixel and 4 consecutive output
+// channels per register quad => 8-byte channel-contiguous NHWC stores, and the "V transposed"
+// store used by the attention kernel ([b][head][d][token]) is lane-contiguous.
+//
+// Tile: 128 pixels x BM couts (BM = 128 | 64) per 256-thread workgroup, 2x2 waves, each wave
+// (BM/2) x 64 via v_mfma_f32_32x32x16_f16; K-step 32, register-staged global->LDS with the next
+// step's loads issued before the current step's MFMAs, LDS rows padded to 80 B (conflict-free
+// ds_read_b128 fragment reads), double-buffered, one barrier per K-step.
+#include "common.h"
+
+#define CV_BN 128
+#define CV_BK 32
+#define CV_LD 40  // halfs per LDS row (32 + 8 pad)
+
+template <int BM, int KW, bool CIN8>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) f16 sW[2][BM * CV_LD];
+  __shared__ __attribute__((aligned(16))) f16 sX[2][CV_BN * CV_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int WM = BM / 2;
+  constexpr int MT = WM / 32;
+  constexpr int NT = 2;
+  constexpr int WROWS = BM / 64;  // weight rows per thread (2 or 1)
+  const int m0 = blockIdx.x * CV_BN;
+  const int c0 = blockIdx.y * BM;
+  const int HoWo = p.Ho * p.Wo;
+  const int ntaps = p.KH * p.KW;
+
+  // ---- per-thread gather rows (fixed over the K loop) ----
+  const int cc = tid & 3;      // 16-byte chunk within the 32-wide K step
+  const int rbase = tid >> 2;  // 0..63
+  long long xbase[2];
+  int iy0[2], ix0[2];
+  bool mval[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    int m = m0 + rbase + 64 * r;
+    mval[r] = m < p.M;
+    int mm = mval[r] ? m : 0;
+    int n = mm / HoWo, rem = mm - n * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[r] = oy * p.stride - p.pad;
+    ix0[r] = ox * p.stride - p.pad;
+    xbase[r] = (long long)n * p.H * p.W * p.Cin;
+  }
+  const f16 *wrow[WROWS];
+#pragma unroll
+  for (int r = 0; r < WROWS; ++r) wrow[r] = p.w + (size_t)(c0 + rbase + 64 * r) * p.Kpad + cc * 8;
+
+  uint4 xreg[2], wreg[WROWS];
+  auto gload = [&](int kt) {
+    const int k = kt * CV_BK + cc * 8;
+    int tap, ci;
+    if (CIN8) {
+      tap = k >> 3;
+      ci = 0;
+    } else {
+      tap = (kt * CV_BK) / p.Cin;
+      ci = k - tap * p.Cin;
+    }
+    const int ky = tap / KW, kx = tap - ky * KW;
+    const bool tval = tap < ntaps;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      int iy = iy0[r] + ky, ix = ix0[r] + kx;
+      bool ok = mval[r] && tval && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *reinterpret_cast<const uint4 *>(p.in + xbase[r] + ((long long)iy * p.W + ix) * p.Cin + ci);
+      xreg[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < WROWS; ++r) wreg[r] = *reinterpret_cast<const uint4 *>(wrow[r] + (size_t)kt * CV_BK);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) *reinterpret_cast<uint4 *>(&sX[buf][(rbase + 64 * r) * CV_LD + cc * 8]) = xreg[r];
+#pragma unroll
+    for (int r = 0; r < WROWS; ++r) *reinterpret_cast<uint4 *>(&sW[buf][(rbase + 64 * r) * CV_LD + cc * 8]) = wreg[r];
+  };
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.Kpad / CV_BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int lr = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[i] = *reinterpret_cast<const half8 *>(&sW[cur][(wm * WM + i * 32 + lr) * CV_LD + ks * 16 + lh * 8]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bf[j] = *reinterpret_cast<const half8 *>(&sX[cur][(wn * 64 + j * 32 + lr) * CV_LD + ks * 16 + lh * 8]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns pixel (lane&31), channels 8*rg + 4*(lane>>5) + [0,4) of each 32x32 tile ----
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int m = m0 + wn * 64 + j * 32 + lr;
+    if (m >= p.M) continue;
+    const bool hi = m >= p.split_m;
+    const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+    const int coff = hi ? p.coff_hi : 0;
+    int prow = 0;
+    if (p.post_add) prow = m % p.post_period;
+    int tb = 0, tt = 0;
+    if (p.out_mode == 2) {
+      tb = m / p.tokens;
+      tt = m - tb * p.tokens;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = c0 + wm * WM + i * 32 + rg * 8 + lh * 4;
+        float v[4];
+        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co);
+        v[0] = acc[i][j][rg * 4 + 0] + bv.x;
+        v[1] = acc[i][j][rg * 4 + 1] + bv.y;
+        v[2] = acc[i][j][rg * 4 + 2] + bv.z;
+        v[3] = acc[i][j][rg * 4 + 3] + bv.w;
+        if (p.res) {
+          half4 rv = *reinterpret_cast<const half4 *>(p.res + (size_t)m * p.Cout + co);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.post_add) {
+          const float4 pv = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + co);
+          v[0] += pv.x;
+          v[1] += pv.y;
+          v[2] += pv.z;
+          v[3] += pv.w;
+        }
+        if (p.out_mode == 0) {
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
+          *reinterpret_cast<half4 *>((f16 *)p.out + orow * p.out_ld + coff + co) = hv;
+        } else if (p.out_mode == 1) {
+          *reinterpret_cast<float4 *>((float *)p.out + orow * p.out_ld + coff + co) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = co + e, h = c >> 7, d = c & 127;
+            ((f16 *)p.out)[(((size_t)tb * 4 + h) * 128 + d) * 416 + tt] = (f16)v[e];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int KW, bool CIN8>
+static int launch_one(const ConvArgs &a, hipStream_t s) {
+  dim3 grid((a.M + CV_BN - 1) / CV_BN, a.Cout / BM);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, KW, CIN8>), grid, dim3(256), 0, s, a);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
+  FP_REQUIRE(a.Cin == 8 || a.Cin % 32 == 0, "conv: Cin=%d must be 8 or a multiple of 32", a.Cin);
+  FP_REQUIRE(a.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", a.Cout);
+  FP_REQUIRE(a.Kpad % CV_BK == 0 && a.Kpad >= a.KH * a.KW * a.Cin, "conv: bad Kpad=%d", a.Kpad);
+  FP_REQUIRE(a.KH == a.KW && (a.KW == 1 || a.KW == 3 || a.KW == 7), "conv: kernel %dx%d unsupported (1,3,7)", a.KH, a.KW);
+  FP_REQUIRE(a.M == a.Nimg * a.Ho * a.Wo, "conv: M mismatch");
+  FP_REQUIRE(a.out_ld % 4 == 0 && a.coff_hi % 4 == 0, "conv: out_ld/coff must be multiples of 4");
+  if (a.M == 0) return FP_OK;
+  const double flops = 2.0 * (double)a.M * a.Cout * a.KH * a.KW * (a.Cin == 8 ? 6 : a.Cin);
+  const char *cls = (a.KW == 3) ? "conv3x3" : (a.KW == 7 ? "conv7x7" : "linear");
+  ProfScope ps(ctx, s, cls, flops);
+  const bool bm128 = (a.Cout % 128 == 0);
+  if (a.Cin == 8) {
+    FP_REQUIRE(a.KW == 7, "conv: Cin=8 path is the 7x7 stem");
+    return bm128 ? launch_one<128, 7, true>(a, s) : launch_one<64, 7, true>(a, s);
+  }
+  if (a.KW == 3) return bm128 ? launch_one<128, 3, false>(a, s) : launch_one<64, 3, false>(a, s);
+  if (a.KW == 1) return bm128 ? launch_one<128, 1, false>(a, s) : launch_one<64, 1, false>(a, s);
+  FP_REQUIRE(false, "conv: unsupported configuration KW=%d Cin=%d", a.KW, a.Cin);
+}

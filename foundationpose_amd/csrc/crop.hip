@@ -1,0 +1,219 @@
+// Observed-frame crops (side B) and depth pre-processing for gfx950.
+//
+// crop_observed: one gather kernel replaces kornia.warp_perspective x2..x5 + the dataset batch
+// transform (predict_pose_refine.py:63,72; predict_score.py:89-90; h5_dataset.py:101-112,158-170).
+// kornia 0.7.2's map (normalise with (size-1), invert, grid_sample(align_corners=False)) collapses,
+// for the axis-aligned crop transform tf = [[sx,0,tx],[0,sy,ty],[0,0,1]], to
+//     x_src = ((i - tx)/sx) * W/(W-1) - 0.5,   y_src = ((j - ty)/sy) * H/(H-1) - 0.5
+// evaluated here in float64 per pixel and rounded once to float32 (oracle/warp.py restates the
+// literal float32 chain; the two agree except where x_src is within ~1e-5 of a rounding boundary).
+// The frame (480x640x(3+3) floats = 7 MB) is L2/MALL resident; every hypothesis re-reads it from
+// cache and the only HBM traffic is the 16 B/pixel network-ready store.
+#include "common.h"
+
+__device__ __forceinline__ float frame_at(const float *img, int H, int W, int C, int y, int x, int c) {
+  return (y >= 0 && y < H && x >= 0 && x < W) ? img[((size_t)y * W + x) * C + c] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void crop_observed_kernel(CropArgs a) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= a.Ho * a.Wo) return;
+  const int j = p / a.Wo, i = p - j * a.Wo;
+  const float *T = a.tf + (size_t)b * 9;
+  const float *pose = a.poses + (size_t)b * 16;
+  const double sx = T[0], tx = T[2], sy = T[4], ty = T[5];
+  const int H = a.H, W = a.W;
+  const double ax = (1.0 / sx) * W / (W - 1.0), bx = (-tx / sx) * W / (W - 1.0) - 0.5;
+  const double ay = (1.0 / sy) * H / (H - 1.0), by = (-ty / sy) * H / (H - 1.0) - 0.5;
+  const float x = (float)(ax * i + bx), y = (float)(ay * j + by);
+
+  // ---- rgb: bilinear, zeros padding (F.grid_sample arithmetic, float32) ----
+  float rgb[3];
+  {
+    float x0f = floorf(x), y0f = floorf(y);
+    int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    float x1f = x0f + 1.f, y1f = y0f + 1.f;
+    float nw = (x1f - x) * (y1f - y), ne = (x - x0f) * (y1f - y), sw = (x1f - x) * (y - y0f), se = (x - x0f) * (y - y0f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+      acc = __fadd_rn(acc, __fmul_rn(frame_at(a.rgb, H, W, 3, y0, x0, c), nw));
+      acc = __fadd_rn(acc, __fmul_rn(frame_at(a.rgb, H, W, 3, y0, x1, c), ne));
+      acc = __fadd_rn(acc, __fmul_rn(frame_at(a.rgb, H, W, 3, y1, x0, c), sw));
+      acc = __fadd_rn(acc, __fmul_rn(frame_at(a.rgb, H, W, 3, y1, x1, c), se));
+      rgb[c] = __fdiv_rn(acc, 255.f);   // h5_dataset.py:123-124
+    }
+  }
+  // ---- geometry: nearest (round half to even), zeros padding ----
+  const int qx = (int)rintf(x), qy = (int)rintf(y);
+  const bool q_in = (qx >= 0 && qx < W && qy >= 0 && qy < H);
+  float xyz[3] = {0.f, 0.f, 0.f};
+  float invalid_thres;
+  if (a.mode == 0) {
+    invalid_thres = 0.001f;
+    if (q_in) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xyz[c] = a.geom[((size_t)qy * W + qx) * 3 + c];
+    }
+  } else {
+    // scorer: depthB crop -> full-res (nearest) -> back-project at full-res pixel (qx,qy) -> crop (nearest)
+    invalid_thres = 0.1f;
+    if (q_in) {
+      // full-res pixel q samples the CROP image at p' (warp with M = tf^-1, src = crop (Ho,Wo), dst = (H,W)):
+      //   p~ = tf * q ;  x' = p~ * Wo/(Wo-1) - 0.5
+      const double cxp = (sx * qx + tx) * a.Wo / (a.Wo - 1.0) - 0.5;
+      const double cyp = (sy * qy + ty) * a.Ho / (a.Ho - 1.0) - 0.5;
+      const int pi = (int)rintf((float)cxp), pj = (int)rintf((float)cyp);
+      float z = 0.f;
+      if (pi >= 0 && pi < a.Wo && pj >= 0 && pj < a.Ho) {
+        const float x2 = (float)(ax * pi + bx), y2 = (float)(ay * pj + by);
+        const int rx = (int)rintf(x2), ry = (int)rintf(y2);
+        if (rx >= 0 && rx < W && ry >= 0 && ry < H) z = a.geom[(size_t)ry * W + rx];
+      }
+      // depth2xyzmap_batch (src/Utils.py:420-438), zfar = inf, float32
+      const float fx = (float)a.K[0], fy = (float)a.K[4], cx = (float)a.K[2], cy = (float)a.K[5];
+      if (!(z < 0.001f)) {
+        xyz[0] = __fdiv_rn(__fmul_rn(__fsub_rn((float)qx, cx), z), fx);
+        xyz[1] = __fdiv_rn(__fmul_rn(__fsub_rn((float)qy, cy), z), fy);
+        xyz[2] = z;
+      }
+    }
+  }
+  // ---- batch transform (h5_dataset.py:104-112 | :162-170) ----
+  const bool invalid = xyz[2] < invalid_thres;
+  const float radius = __fdiv_rn(a.mesh_diameter, 2.f);
+  const float inv_r = __fdiv_rn(1.f, radius);
+  float o6[6] = {rgb[0], rgb[1], rgb[2], 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = __fsub_rn(xyz[c], pose[c * 4 + 3]);
+    if (a.normalize_xyz) {
+      v = __fmul_rn(v, inv_r);
+      if (invalid || fabsf(v) >= 2.f) v = 0.f;
+    }
+    o6[3 + c] = v;
+  }
+  if (a.out_fmt == 0) {
+    float *out = (float *)a.out + (size_t)b * 6 * a.Ho * a.Wo;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out[(size_t)c * a.Ho * a.Wo + p] = o6[c];
+  } else {
+    half8 hv;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) hv[c] = (f16)o6[c];
+    hv[6] = (f16)0.f;
+    hv[7] = (f16)0.f;
+    *reinterpret_cast<half8 *>((f16 *)a.out + ((size_t)b * a.Ho * a.Wo + p) * 8) = hv;
+  }
+}
+
+int launch_crop_observed(const CropArgs &a, hipStream_t s) {
+  FP_REQUIRE(a.mode == 0 || a.mode == 1, "crop_observed: mode must be 0 (refiner) or 1 (scorer)");
+  FP_REQUIRE(a.H > 1 && a.W > 1 && a.Ho > 1 && a.Wo > 1, "crop_observed: degenerate image size");
+  if (a.N == 0) return FP_OK;
+  dim3 grid((a.Ho * a.Wo + 255) / 256, a.N);
+  hipLaunchKernelGGL(crop_observed_kernel, grid, dim3(256), 0, s, a);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// depth pre-processing: the reference's NVIDIA Warp kernels (src/Utils.py:304-395), one thread/pixel
+// ----------------------------------------------------------------------------------------------
+__global__ void erode_depth_kernel(const float *__restrict__ depth, int H, int W, int radius, float diff_thres, float ratio_thres,
+                                   float zfar, float *__restrict__ out) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y * blockDim.y + threadIdx.y;
+  if (w >= W || h >= H) return;
+  float d_ori = depth[(size_t)h * W + w];
+  float bad = 0.f, total = 0.f;
+  for (int u = w - radius; u <= w + radius; ++u) {
+    if (u < 0 || u >= W) continue;
+    for (int v = h - radius; v <= h + radius; ++v) {
+      if (v < 0 || v >= H) continue;
+      float cur = depth[(size_t)v * W + u];
+      total += 1.f;
+      if (cur < 0.001f || cur >= zfar || fabsf(cur - d_ori) > diff_thres) bad += 1.f;
+    }
+  }
+  out[(size_t)h * W + w] = (__fdiv_rn(bad, total) > ratio_thres) ? 0.f : d_ori;
+}
+
+__global__ void bilateral_depth_kernel(const float *__restrict__ depth, int H, int W, int radius, float zfar, float sigmaD,
+                                       float sigmaR, float *__restrict__ out) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y * blockDim.y + threadIdx.y;
+  if (w >= W || h >= H) return;
+  float mean_depth = 0.f;
+  int num_valid = 0;
+  for (int u = w - radius; u <= w + radius; ++u) {
+    if (u < 0 || u >= W) continue;
+    for (int v = h - radius; v <= h + radius; ++v) {
+      if (v < 0 || v >= H) continue;
+      float cur = depth[(size_t)v * W + u];
+      if (cur >= 0.001f && cur < zfar) {
+        num_valid += 1;
+        mean_depth = __fadd_rn(mean_depth, cur);
+      }
+    }
+  }
+  float res = 0.f;
+  if (num_valid > 0) {
+    mean_depth = __fdiv_rn(mean_depth, (float)num_valid);
+    float dc = depth[(size_t)h * W + w];
+    float sum_w = 0.f, sum = 0.f;
+    const float den_d = __fmul_rn(__fmul_rn(2.f, sigmaD), sigmaD), den_r = __fmul_rn(__fmul_rn(2.f, sigmaR), sigmaR);
+    for (int u = w - radius; u <= w + radius; ++u) {
+      if (u < 0 || u >= W) continue;
+      for (int v = h - radius; v <= h + radius; ++v) {
+        if (v < 0 || v >= H) continue;
+        float cur = depth[(size_t)v * W + u];
+        if (cur >= 0.001f && cur < zfar && fabsf(cur - mean_depth) < 0.01f) {
+          float sp = __fdiv_rn(-(float)((u - w) * (u - w) + (h - v) * (h - v)), den_d);
+          float df = __fsub_rn(dc, cur);
+          float rg = __fdiv_rn(__fmul_rn(df, df), den_r);
+          float wt = expf(__fsub_rn(sp, rg));
+          sum_w = __fadd_rn(sum_w, wt);
+          sum = __fadd_rn(sum, __fmul_rn(wt, cur));
+        }
+      }
+    }
+    if (sum_w > 0.f) res = __fdiv_rn(sum, sum_w);
+  }
+  out[(size_t)h * W + w] = res;
+}
+
+__global__ void depth2xyz_kernel(const float *__restrict__ depth, int H, int W, float fx, float fy, float cx, float cy, float zfar,
+                                 float *__restrict__ xyz) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y * blockDim.y + threadIdx.y;
+  if (w >= W || h >= H) return;
+  float z = depth[(size_t)h * W + w];
+  float o[3] = {0.f, 0.f, 0.f};
+  if (!(z < 0.001f) && !(z > zfar)) {
+    o[0] = __fdiv_rn(__fmul_rn(__fsub_rn((float)w, cx), z), fx);
+    o[1] = __fdiv_rn(__fmul_rn(__fsub_rn((float)h, cy), z), fy);
+    o[2] = z;
+  }
+  size_t p = ((size_t)h * W + w) * 3;
+  xyz[p] = o[0];
+  xyz[p + 1] = o[1];
+  xyz[p + 2] = o[2];
+}
+
+static dim3 grid2d(int H, int W) { return dim3((W + 31) / 32, (H + 7) / 8); }
+
+int launch_erode(const float *d, int H, int W, int radius, float diff_thres, float ratio_thres, float zfar, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(erode_depth_kernel, grid2d(H, W), dim3(32, 8), 0, s, d, H, W, radius, diff_thres, ratio_thres, zfar, out);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+int launch_bilateral(const float *d, int H, int W, int radius, float zfar, float sigmaD, float sigmaR, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(bilateral_depth_kernel, grid2d(H, W), dim3(32, 8), 0, s, d, H, W, radius, zfar, sigmaD, sigmaR, out);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+int launch_depth2xyz(const float *d, int H, int W, const double *K, float zfar, float *xyz, hipStream_t s) {
+  hipLaunchKernelGGL(depth2xyz_kernel, grid2d(H, W), dim3(32, 8), 0, s, d, H, W, (float)K[0], (float)K[4], (float)K[2], (float)K[5],
+                     zfar, xyz);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}

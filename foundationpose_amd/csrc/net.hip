@@ -1,0 +1,447 @@
+// Network weights (state_dict -> folded, packed device buffers) and the forward schedules of
+// RefineNet (learning/models/refine_network.py:73-93) and ScoreNetMultiPair
+// (learning/models/score_network.py:60-90) as sequences of the gfx950 kernels in conv.hip / attn.hip.
+#include "common.h"
+
+#include <cmath>
+#include <memory>
+
+struct ConvW {
+  f16 *w = nullptr;
+  float *bias = nullptr;
+  int Cin = 0, Cout = 0, K = 1, Kpad = 0, stride = 1;
+};
+
+struct HeadW {  // one nn.TransformerEncoderLayer + Linear
+  ConvW qk, v, out, ff1, ff2;
+  float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr, *hw = nullptr, *hb = nullptr;
+  int out_dim = 0;
+};
+
+struct LinF32 {
+  float *w = nullptr, *b = nullptr;
+  int N = 0, K = 0;
+};
+
+struct fp_net {
+  int kind = 0, use_bn = 1;
+  ConvW trunk[15];
+  float *pe = nullptr;  // 400 x 512
+  HeadW heads[2];       // refine: trans, rot
+  ConvW att_qk, att_v;  // score: self.att in_proj on tokens
+  LinF32 att_out, cross_in, cross_out, lin;
+  std::vector<void *> allocs;
+};
+
+namespace {
+
+struct SD {
+  std::map<std::string, const fp_tensor *> m;
+  const fp_tensor *get(const std::string &k) const {
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : it->second;
+  }
+};
+
+int need(const SD &sd, const std::string &k, int ndim, std::initializer_list<int64_t> shape, const fp_tensor **out) {
+  const fp_tensor *t = sd.get(k);
+  if (!t) {
+    fp_set_error("state_dict: missing key '%s'", k.c_str());
+    return FP_EKEY;
+  }
+  if (t->ndim != ndim) {
+    fp_set_error("state_dict: '%s' has ndim %d, expected %d", k.c_str(), t->ndim, ndim);
+    return FP_EKEY;
+  }
+  int i = 0;
+  for (int64_t s : shape) {
+    if (s >= 0 && t->shape[i] != s) {
+      fp_set_error("state_dict: '%s' dim %d is %lld, expected %lld", k.c_str(), i, (long long)t->shape[i], (long long)s);
+      return FP_EKEY;
+    }
+    ++i;
+  }
+  *out = t;
+  return FP_OK;
+}
+
+template <typename T>
+int upload(fp_net *net, const std::vector<T> &h, T **d) {
+  void *p = nullptr;
+  FP_CHECK_HIP(hipMalloc(&p, h.size() * sizeof(T)));
+  net->allocs.push_back(p);
+  FP_CHECK_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *d = (T *)p;
+  return FP_OK;
+}
+
+// conv (+ optional BatchNorm eval fold): y = (conv(x,w)+b - mean) * gamma/sqrt(var+eps) + beta
+int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::string &bnkey, bool use_bn, int stride, ConvW *out) {
+  const fp_tensor *w, *b;
+  FP_TRY(need(sd, wkey + ".weight", 4, {-1, -1, -1, -1}, &w));
+  const int Cout = (int)w->shape[0], Cin = (int)w->shape[1], K = (int)w->shape[2];
+  FP_REQUIRE(w->shape[3] == K, "conv '%s' is not square", wkey.c_str());
+  FP_TRY(need(sd, wkey + ".bias", 1, {Cout}, &b));
+  std::vector<float> scale(Cout, 1.f), shift(Cout, 0.f);
+  if (use_bn) {
+    const fp_tensor *g, *be, *mu, *var;
+    FP_TRY(need(sd, bnkey + ".weight", 1, {Cout}, &g));
+    FP_TRY(need(sd, bnkey + ".bias", 1, {Cout}, &be));
+    FP_TRY(need(sd, bnkey + ".running_mean", 1, {Cout}, &mu));
+    FP_TRY(need(sd, bnkey + ".running_var", 1, {Cout}, &var));
+    for (int c = 0; c < Cout; ++c) {
+      scale[c] = g->data[c] / std::sqrt(var->data[c] + 1e-5f);
+      shift[c] = be->data[c] - mu->data[c] * scale[c];
+    }
+  }
+  const int CinP = (Cin < 8) ? 8 : Cin;
+  FP_REQUIRE(CinP == 8 || CinP % 32 == 0, "conv '%s': Cin=%d unsupported", wkey.c_str(), Cin);
+  const int Kraw = K * K * CinP, Kpad = (Kraw + 31) / 32 * 32;
+  std::vector<f16> hw((size_t)Cout * Kpad, (f16)0.f);
+  std::vector<float> hb(Cout);
+  for (int co = 0; co < Cout; ++co) {
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int ky = 0; ky < K; ++ky)
+        for (int kx = 0; kx < K; ++kx)
+          hw[(size_t)co * Kpad + (ky * K + kx) * CinP + ci] = (f16)(w->data[(((size_t)co * Cin + ci) * K + ky) * K + kx] * scale[co]);
+    hb[co] = b->data[co] * scale[co] + shift[co];
+  }
+  out->Cin = CinP;
+  out->Cout = Cout;
+  out->K = K;
+  out->Kpad = Kpad;
+  out->stride = stride;
+  FP_TRY(upload(net, hw, &out->w));
+  FP_TRY(upload(net, hb, &out->bias));
+  return FP_OK;
+}
+
+// rows [r0, r1) of a (R, K) linear weight as a 1x1 "conv"
+int make_linear(fp_net *net, const SD &sd, const std::string &wkey, const std::string &bkey, int r0, int r1, int K, ConvW *out) {
+  const fp_tensor *w, *b;
+  FP_TRY(need(sd, wkey, 2, {-1, K}, &w));
+  FP_TRY(need(sd, bkey, 1, {w->shape[0]}, &b));
+  FP_REQUIRE(r1 <= w->shape[0], "linear '%s': rows out of range", wkey.c_str());
+  const int N = r1 - r0;
+  std::vector<f16> hw((size_t)N * K);
+  std::vector<float> hb(N);
+  for (int n = 0; n < N; ++n) {
+    for (int k = 0; k < K; ++k) hw[(size_t)n * K + k] = (f16)w->data[(size_t)(r0 + n) * K + k];
+    hb[n] = b->data[r0 + n];
+  }
+  out->Cin = K;
+  out->Cout = N;
+  out->K = 1;
+  out->Kpad = K;
+  out->stride = 1;
+  FP_TRY(upload(net, hw, &out->w));
+  FP_TRY(upload(net, hb, &out->bias));
+  return FP_OK;
+}
+
+int make_vec(fp_net *net, const SD &sd, const std::string &key, int n, float **out) {
+  const fp_tensor *t = sd.get(key);
+  if (!t) {
+    fp_set_error("state_dict: missing key '%s'", key.c_str());
+    return FP_EKEY;
+  }
+  int64_t tot = 1;
+  for (int i = 0; i < t->ndim; ++i) tot *= t->shape[i];
+  FP_REQUIRE(tot == n, "state_dict: '%s' has %lld elements, expected %d", key.c_str(), (long long)tot, n);
+  std::vector<float> h(t->data, t->data + n);
+  return upload(net, h, out);
+}
+
+int make_linf32(fp_net *net, const SD &sd, const std::string &wkey, const std::string &bkey, int N, int K, LinF32 *out) {
+  out->N = N;
+  out->K = K;
+  FP_TRY(make_vec(net, sd, wkey, N * K, &out->w));
+  FP_TRY(make_vec(net, sd, bkey, N, &out->b));
+  return FP_OK;
+}
+
+int make_trunk(fp_net *net, const SD &sd, const std::string &eA, const std::string &eAB, bool bn) {
+  auto cbr = [&](const std::string &pre, int stride, ConvW *o) { return make_conv(net, sd, pre + ".net.0", pre + ".net.1", bn, stride, o); };
+  auto res = [&](const std::string &pre, ConvW *o1, ConvW *o2) {
+    FP_TRY(make_conv(net, sd, pre + ".conv1", pre + ".bn1", bn, 1, o1));
+    return make_conv(net, sd, pre + ".conv2", pre + ".bn2", bn, 1, o2);
+  };
+  ConvW *t = net->trunk;
+  FP_TRY(cbr(eA + ".0", 2, &t[0]));
+  FP_TRY(cbr(eA + ".1", 2, &t[1]));
+  FP_TRY(res(eA + ".2", &t[2], &t[3]));
+  FP_TRY(res(eA + ".3", &t[4], &t[5]));
+  FP_TRY(res(eAB + ".0", &t[6], &t[7]));
+  FP_TRY(res(eAB + ".1", &t[8], &t[9]));
+  FP_TRY(cbr(eAB + ".2", 2, &t[10]));
+  FP_TRY(res(eAB + ".3", &t[11], &t[12]));
+  FP_TRY(res(eAB + ".4", &t[13], &t[14]));
+  FP_REQUIRE(t[0].Cin == 8 && t[0].Cout == 64 && t[0].K == 7 && t[1].Cout == 128 && t[6].Cin == 256 && t[10].Cout == 512,
+             "trunk: unexpected layer shapes (c_in must be <= 8 -> padded to 8)");
+  FP_TRY(make_vec(net, sd, "pos_embed.pe", 400 * 512, &net->pe));
+  return FP_OK;
+}
+
+}  // namespace
+
+extern "C" int fp_net_create(fp_ctx *ctx, int kind, const fp_tensor *tensors, int n_tensors, int use_bn, fp_net **out) {
+  FP_REQUIRE(ctx && tensors && out, "fp_net_create: null argument");
+  FP_REQUIRE(kind == FP_NET_REFINE || kind == FP_NET_SCORE, "fp_net_create: kind must be FP_NET_REFINE or FP_NET_SCORE");
+  FP_CHECK_HIP(hipSetDevice(ctx->device));
+  SD sd;
+  for (int i = 0; i < n_tensors; ++i) sd.m[tensors[i].name] = &tensors[i];
+  std::unique_ptr<fp_net> net(new fp_net);
+  net->kind = kind;
+  net->use_bn = use_bn;
+  int rc = FP_OK;
+  auto run = [&]() -> int {
+    if (kind == FP_NET_REFINE) {
+      FP_TRY(make_trunk(net.get(), sd, "encodeA", "encodeAB", use_bn));
+      const char *names[2] = {"trans_head", "rot_head"};
+      for (int h = 0; h < 2; ++h) {
+        HeadW &H = net->heads[h];
+        std::string p = std::string(names[h]) + ".0";
+        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 0, 1024, 512, &H.qk));
+        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 1024, 1536, 512, &H.v));
+        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", 0, 512, 512, &H.out));
+        FP_TRY(make_linear(net.get(), sd, p + ".linear1.weight", p + ".linear1.bias", 0, 512, 512, &H.ff1));
+        FP_TRY(make_linear(net.get(), sd, p + ".linear2.weight", p + ".linear2.bias", 0, 512, 512, &H.ff2));
+        FP_TRY(make_vec(net.get(), sd, p + ".norm1.weight", 512, &H.ln1g));
+        FP_TRY(make_vec(net.get(), sd, p + ".norm1.bias", 512, &H.ln1b));
+        FP_TRY(make_vec(net.get(), sd, p + ".norm2.weight", 512, &H.ln2g));
+        FP_TRY(make_vec(net.get(), sd, p + ".norm2.bias", 512, &H.ln2b));
+        const fp_tensor *hw;
+        FP_TRY(need(sd, std::string(names[h]) + ".1.weight", 2, {-1, 512}, &hw));
+        H.out_dim = (int)hw->shape[0];
+        FP_REQUIRE(H.out_dim >= 1 && H.out_dim <= 6, "head '%s': out_dim %d unsupported", names[h], H.out_dim);
+        FP_TRY(make_vec(net.get(), sd, std::string(names[h]) + ".1.weight", H.out_dim * 512, &H.hw));
+        FP_TRY(make_vec(net.get(), sd, std::string(names[h]) + ".1.bias", H.out_dim, &H.hb));
+      }
+    } else {
+      FP_TRY(make_trunk(net.get(), sd, "encoderA", "encoderAB", use_bn));
+      FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 0, 1024, 512, &net->att_qk));
+      FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 1024, 1536, 512, &net->att_v));
+      FP_TRY(make_linf32(net.get(), sd, "att.out_proj.weight", "att.out_proj.bias", 512, 512, &net->att_out));
+      FP_TRY(make_linf32(net.get(), sd, "att_cross.in_proj_weight", "att_cross.in_proj_bias", 1536, 512, &net->cross_in));
+      FP_TRY(make_linf32(net.get(), sd, "att_cross.out_proj.weight", "att_cross.out_proj.bias", 512, 512, &net->cross_out));
+      FP_TRY(make_linf32(net.get(), sd, "linear.weight", "linear.bias", 1, 512, &net->lin));
+    }
+    return FP_OK;
+  };
+  rc = run();
+  if (rc != FP_OK) {
+    for (void *p : net->allocs) (void)hipFree(p);
+    return rc;
+  }
+  *out = net.release();
+  return FP_OK;
+}
+
+extern "C" int fp_net_destroy(fp_net *net) {
+  if (!net) return FP_OK;
+  for (void *p : net->allocs) (void)hipFree(p);
+  delete net;
+  return FP_OK;
+}
+
+extern "C" int fp_net_rot_dim(const fp_net *net) { return (net && net->kind == FP_NET_REFINE) ? net->heads[1].out_dim : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// forward schedules
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Conv2dCall {
+  const f16 *in;
+  int Nimg, H, W;
+  const ConvW *cw;
+  const f16 *res = nullptr;
+  int relu = 1;
+  void *out = nullptr;
+  int out_mode = 0;
+  int out_ld = 0, split_m = 0x7fffffff, coff_hi = 0;
+  const float *post_add = nullptr;
+  int post_period = 1;
+  int tokens = 400;
+};
+
+int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s) {
+  ConvArgs a;
+  const ConvW &w = *c.cw;
+  a.in = c.in;
+  a.w = w.w;
+  a.bias = w.bias;
+  a.res = c.res;
+  a.post_add = c.post_add;
+  a.out = c.out;
+  a.Nimg = c.Nimg;
+  a.H = c.H;
+  a.W = c.W;
+  a.Cin = w.Cin;
+  a.KH = a.KW = w.K;
+  a.stride = w.stride;
+  a.pad = (w.K - 1) / 2;
+  a.Ho = (c.H + 2 * a.pad - w.K) / w.stride + 1;
+  a.Wo = (c.W + 2 * a.pad - w.K) / w.stride + 1;
+  a.Cout = w.Cout;
+  a.Kpad = w.Kpad;
+  a.M = c.Nimg * a.Ho * a.Wo;
+  a.relu = c.relu;
+  a.out_mode = c.out_mode;
+  a.out_ld = c.out_ld ? c.out_ld : w.Cout;
+  a.split_m = c.split_m;
+  a.coff_hi = c.coff_hi;
+  a.post_period = c.post_period;
+  a.tokens = c.tokens;
+  return launch_conv(ctx, a, s);
+}
+
+#define TAKE(ptr, type, count)                                                            \
+  type *ptr = (type *)ctx->arena.take((size_t)(count) * sizeof(type));                    \
+  if (!ptr) {                                                                             \
+    fp_set_error("arena exhausted (%s); call fp_ctx_reserve with a larger max_hyp", #ptr); \
+    return FP_ENOMEM;                                                                     \
+  }
+
+// shared trunk -> tokens (N*400, 512) fp16, positional embedding added
+int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *x, int N, f16 **tokens_out, hipStream_t s) {
+  const ConvW *t = net->trunk;
+  const size_t n2 = (size_t)2 * N;
+  TAKE(a0, f16, n2 * 80 * 80 * 64);
+  TAKE(a1, f16, n2 * 40 * 40 * 128);
+  TAKE(tA, f16, n2 * 40 * 40 * 128);
+  TAKE(a2, f16, n2 * 40 * 40 * 128);
+  TAKE(ab0, f16, (size_t)N * 40 * 40 * 256);
+  TAKE(tB, f16, (size_t)N * 40 * 40 * 256);
+  TAKE(ab1, f16, (size_t)N * 40 * 40 * 256);
+  TAKE(c0, f16, (size_t)N * 400 * 512);
+  TAKE(tC, f16, (size_t)N * 400 * 512);
+  TAKE(c1, f16, (size_t)N * 400 * 512);
+  TAKE(tok, f16, (size_t)N * 400 * 512);
+  Conv2dCall c;
+  // encodeA / encoderA on cat([A,B],0)
+  c = Conv2dCall{x, (int)n2, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{a0, (int)n2, 80, 80, &t[1]}; c.out = a1; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{a1, (int)n2, 40, 40, &t[2]}; c.out = tA; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{tA, (int)n2, 40, 40, &t[3]}; c.res = a1; c.out = a2; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{a2, (int)n2, 40, 40, &t[4]}; c.out = tA; FP_TRY(run_conv(ctx, c, s));
+  // last conv of encodeA writes the channel-concat cat((a,b),1) directly: image n<N -> channels [0,128), n>=N -> [128,256)
+  c = Conv2dCall{tA, (int)n2, 40, 40, &t[5]}; c.res = a2; c.out = ab0; c.out_ld = 256; c.split_m = N * 1600; c.coff_hi = 128;
+  FP_TRY(run_conv(ctx, c, s));
+  // encodeAB
+  c = Conv2dCall{ab0, N, 40, 40, &t[6]}; c.out = tB; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{tB, N, 40, 40, &t[7]}; c.res = ab0; c.out = ab1; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{ab1, N, 40, 40, &t[8]}; c.out = tB; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{tB, N, 40, 40, &t[9]}; c.res = ab1; c.out = ab0; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{ab0, N, 40, 40, &t[10]}; c.out = c0; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{c0, N, 20, 20, &t[11]}; c.out = tC; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{tC, N, 20, 20, &t[12]}; c.res = c0; c.out = c1; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{c1, N, 20, 20, &t[13]}; c.out = tC; FP_TRY(run_conv(ctx, c, s));
+  // reshape(bs,C,-1).permute(0,2,1) is the NHWC tensor itself; pos_embed.pe added in the epilogue
+  c = Conv2dCall{tC, N, 20, 20, &t[14]}; c.res = c1; c.out = tok; c.post_add = net->pe; c.post_period = 400;
+  FP_TRY(run_conv(ctx, c, s));
+  *tokens_out = tok;
+  return FP_OK;
+}
+
+// q|k and transposed-v projections + fused attention: tokens (M,512) -> att (M,512)
+int run_mha_core(fp_ctx *ctx, const ConvW &qkw, const ConvW &vw, const f16 *tok, int N, f16 *qk, f16 *vt, f16 *att, hipStream_t s) {
+  const int M = N * 400;
+  Conv2dCall c;
+  c = Conv2dCall{tok, M, 1, 1, &qkw}; c.relu = 0; c.out = qk; FP_TRY(run_conv(ctx, c, s));
+  FP_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)N * 4 * 128 * 416 * sizeof(f16), s));
+  c = Conv2dCall{tok, M, 1, 1, &vw}; c.relu = 0; c.out = vt; c.out_mode = 2; c.tokens = 400; FP_TRY(run_conv(ctx, c, s));
+  return launch_attention(ctx, qk, vt, N, 400, att, s);
+}
+
+}  // namespace
+
+extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot,
+                                 void *stream) {
+  FP_REQUIRE(ctx && net && d_net_in && d_trans && d_rot, "fp_refine_forward: null argument");
+  FP_REQUIRE(net->kind == FP_NET_REFINE, "fp_refine_forward: not a RefineNet");
+  FP_REQUIRE(N >= 0, "fp_refine_forward: N<0");
+  if (N == 0) return FP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(N)));
+  const size_t mark = ctx->arena.off;
+  auto body = [&]() -> int {
+    f16 *tok = nullptr;
+    FP_TRY(run_trunk(ctx, net, (const f16 *)d_net_in, N, &tok, s));
+    const int M = N * 400;
+    TAKE(qk, f16, (size_t)M * 1024);
+    TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
+    TAKE(att, f16, (size_t)M * 512);
+    TAKE(y32, float, (size_t)M * 512);
+    TAKE(x1, f16, (size_t)M * 512);
+    TAKE(ff, f16, (size_t)M * 512);
+    float *outs[2] = {d_trans, d_rot};
+    for (int h = 0; h < 2; ++h) {
+      const HeadW &H = net->heads[h];
+      FP_TRY(run_mha_core(ctx, H.qk, H.v, tok, N, qk, vt, att, s));
+      Conv2dCall c;
+      c = Conv2dCall{att, M, 1, 1, &H.out}; c.relu = 0; c.res = tok; c.out = y32; c.out_mode = 1; FP_TRY(run_conv(ctx, c, s));
+      FP_TRY(launch_layernorm(y32, H.ln1g, H.ln1b, M, x1, s));
+      c = Conv2dCall{x1, M, 1, 1, &H.ff1}; c.relu = 1; c.out = ff; FP_TRY(run_conv(ctx, c, s));
+      c = Conv2dCall{ff, M, 1, 1, &H.ff2}; c.relu = 0; c.res = x1; c.out = y32; c.out_mode = 1; FP_TRY(run_conv(ctx, c, s));
+      FP_TRY(launch_ln_mean_head(y32, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], s));
+    }
+    return FP_OK;
+  };
+  int rc = body();
+  ctx->arena.off = mark;
+  return rc;
+}
+
+extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, void *stream) {
+  FP_REQUIRE(ctx && net && d_net_in && d_feats, "fp_score_features: null argument");
+  FP_REQUIRE(net->kind == FP_NET_SCORE, "fp_score_features: not a ScoreNetMultiPair");
+  FP_REQUIRE(N >= 0, "fp_score_features: N<0");
+  if (N == 0) return FP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(N)));
+  const size_t mark = ctx->arena.off;
+  auto body = [&]() -> int {
+    f16 *tok = nullptr;
+    FP_TRY(run_trunk(ctx, net, (const f16 *)d_net_in, N, &tok, s));
+    const int M = N * 400;
+    TAKE(qk, f16, (size_t)M * 1024);
+    TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
+    TAKE(att, f16, (size_t)M * 512);
+    TAKE(mean, float, (size_t)N * 512);
+    FP_TRY(run_mha_core(ctx, net->att_qk, net->att_v, tok, N, qk, vt, att, s));
+    // mean over tokens commutes with out_proj (score_network.py:73-74)
+    FP_TRY(launch_token_mean(att, N, 400, mean, s));
+    FP_TRY(launch_small_linear(mean, net->att_out.w, net->att_out.b, N, 512, 512, d_feats, s));
+    return FP_OK;
+  };
+  int rc = body();
+  ctx->arena.off = mark;
+  return rc;
+}
+
+extern "C" int fp_score_tail(fp_ctx *ctx, const fp_net *net, const float *d_feats, int groups, int L, float *d_logits,
+                             int32_t *d_argmax, void *stream) {
+  FP_REQUIRE(ctx && net && d_feats && d_logits, "fp_score_tail: null argument");
+  FP_REQUIRE(net->kind == FP_NET_SCORE, "fp_score_tail: not a ScoreNetMultiPair");
+  FP_REQUIRE(groups >= 0 && L >= 1, "fp_score_tail: bad groups/L");
+  if (groups == 0) return FP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int M = groups * L;
+  FP_TRY(fp_arena_ensure(ctx, (size_t)M * (1536 + 512 + 512) * 4 + (1 << 20)));
+  const size_t mark = ctx->arena.off;
+  auto body = [&]() -> int {
+    TAKE(qkv, float, (size_t)M * 1536);
+    TAKE(ca, float, (size_t)M * 512);
+    TAKE(co, float, (size_t)M * 512);
+    FP_TRY(launch_small_linear(d_feats, net->cross_in.w, net->cross_in.b, M, 512, 1536, qkv, s));
+    FP_TRY(launch_cross_attention(qkv, groups, L, ca, s));
+    FP_TRY(launch_small_linear(ca, net->cross_out.w, net->cross_out.b, M, 512, 512, co, s));
+    FP_TRY(launch_small_linear(co, net->lin.w, net->lin.b, M, 512, 1, d_logits, s));
+    if (d_argmax) FP_TRY(launch_argmax(d_logits, groups, L, d_argmax, s));
+    return FP_OK;
+  };
+  int rc = body();
+  ctx->arena.off = mark;
+  return rc;
+}

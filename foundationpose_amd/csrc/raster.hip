@@ -1,0 +1,371 @@
+// Batched pose-hypothesis rasteriser for gfx950 (replaces nvdiffrast in src/Utils.py:133-219) and the
+// crop-window transform (src/Utils.py:577-621).
+//
+// Regime: a 160x160 crop of a ~16k-face mesh => triangles are 1-3 pixels ("micro-polygons").  A
+// sort-middle tile binner would spend its time binning; instead the FRAMEBUFFER lives in LDS and the
+// triangles stream through the CU:
+//   one workgroup = one hypothesis x one horizontal strip of the crop (80 rows x 160 px x 8 B = 100 KiB
+//   of the 160 KiB LDS); every lane sets up whole triangles (vertex transform as fmaf chains, 1/16-px
+//   snapping, 64-bit integer edge functions, top-left rule) and resolves visibility with one
+//   ds_min_u64 per covered pixel on the packed key (ordered z/w : 32 | face id : 32) - nearest wins,
+//   ties go to the lower face id, independent of lane scheduling => bit-reproducible.
+//   A second pass resolves each pixel: perspective-correct barycentrics, attribute interpolation,
+//   shading, and either fp32 channels-last maps (API parity with nvdiffrast_render) or the fused
+//   network-ready fp16 NHWC8 tensor (rgb, (xyz-t)*2/diam with invalid masking; h5_dataset.py:92-99),
+//   written as one coalesced 16-byte store per pixel.
+// The arithmetic is mirrored 1:1 by oracle/raster_c.c.
+#include "common.h"
+
+#define RB_THREADS 1024
+
+__device__ __forceinline__ unsigned ordered_key(float z) {
+  unsigned b = __float_as_uint(z);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct Vtx {
+  int X, Y;
+  float w, zn;
+  bool ok;
+};
+
+__device__ __forceinline__ Vtx xform_vertex(const float *__restrict__ pos, int v, const float *M, float hw, float hh) {
+  float px = pos[v * 3], py = pos[v * 3 + 1], pz = pos[v * 3 + 2];
+  float c0 = fmaf(M[0], px, fmaf(M[1], py, fmaf(M[2], pz, M[3])));
+  float c1 = fmaf(M[4], px, fmaf(M[5], py, fmaf(M[6], pz, M[7])));
+  float c2 = fmaf(M[8], px, fmaf(M[9], py, fmaf(M[10], pz, M[11])));
+  float c3 = fmaf(M[12], px, fmaf(M[13], py, fmaf(M[14], pz, M[15])));
+  Vtx o;
+  o.w = c3;
+  o.ok = false;
+  o.X = o.Y = 0;
+  o.zn = 0.f;
+  if (c3 > 0.f) {
+    float xn = c0 / c3, yn = c1 / c3;
+    o.zn = c2 / c3;
+    float sx = fmaf(xn, hw, hw), sy = fmaf(yn, hh, hh);
+    if (fabsf(sx) <= 1e6f && fabsf(sy) <= 1e6f) {
+      o.X = (int)rintf(sx * 16.f);
+      o.Y = (int)rintf(sy * 16.f);
+      o.ok = true;
+    }
+  }
+  return o;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int strip_rows, int n_strips) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];
+  __shared__ float sM[16];
+  __shared__ float sP[12];
+  const int b = blockIdx.x / n_strips, strip = blockIdx.x % n_strips;
+  const int Ho = a.Ho, Wo = a.Wo;
+  const int row0 = strip * strip_rows;  // GL (bottom-up) rows [row0, row1)
+  const int row1 = min(Ho, row0 + strip_rows);
+  const int npix = (row1 - row0) * Wo;
+  const float *pose = a.poses + (size_t)b * 16;
+
+  if (threadIdx.x == 0) {
+    // clip matrix in float64, rounded once (oracle/render.py: clip_matrices; src/Utils.py:155-181)
+    const double W = a.W, H = a.H, zn = 0.001, zf = 100.0;
+    double P[16] = {2 * a.K[0] / W, -2 * a.K[1] / W, (-2 * a.K[2] + W) / W, 0,
+                    0, 2 * a.K[4] / H, (2 * a.K[5] - H) / H, 0,
+                    0, 0, -(zf + zn) / (zf - zn), -2 * (zf * zn) / (zf - zn),
+                    0, 0, -1, 0};
+    double G[16];  // glcam_in_cvcam @ ob_in_cam : negate rows 1,2
+    for (int c = 0; c < 4; ++c) {
+      G[c] = pose[c];
+      G[4 + c] = -(double)pose[4 + c];
+      G[8 + c] = -(double)pose[8 + c];
+      G[12 + c] = pose[12 + c];
+    }
+    double Mx[16];
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) {
+        double s = 0;
+        for (int k = 0; k < 4; ++k) s += P[r * 4 + k] * G[k * 4 + c];
+        Mx[r * 4 + c] = s;
+      }
+    if (a.bbox2d) {
+      const float *bb = a.bbox2d + (size_t)b * 4;
+      double l = bb[0], t = H - (double)bb[1], r = bb[2], bt = H - (double)bb[3];
+      double t00 = W / (r - l), t11 = H / (t - bt), t30 = (W - r - l) / (r - l), t31 = (H - t - bt) / (t - bt);
+      for (int c = 0; c < 4; ++c) {
+        double r3 = Mx[12 + c];
+        Mx[c] = t00 * Mx[c] + t30 * r3;
+        Mx[4 + c] = t11 * Mx[4 + c] + t31 * r3;
+      }
+    }
+    for (int i = 0; i < 16; ++i) sM[i] = (float)Mx[i];
+    for (int i = 0; i < 12; ++i) sP[i] = pose[i];
+  }
+  for (int i = threadIdx.x; i < npix; i += RB_THREADS) zbuf[i] = ~0ull;
+  __syncthreads();
+
+  float M[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) M[i] = sM[i];
+  const float hw = 0.5f * (float)Wo, hh = 0.5f * (float)Ho;
+  const MeshDev &m = a.mesh;
+
+  // ---- pass 1: stream triangles, resolve visibility in LDS ----
+  for (int t = threadIdx.x; t < m.F; t += RB_THREADS) {
+    int i0 = m.faces[t * 3], i1 = m.faces[t * 3 + 1], i2 = m.faces[t * 3 + 2];
+    Vtx v0 = xform_vertex(m.pos, i0, M, hw, hh);
+    Vtx v1 = xform_vertex(m.pos, i1, M, hw, hh);
+    Vtx v2 = xform_vertex(m.pos, i2, M, hw, hh);
+    if (!(v0.ok && v1.ok && v2.ok)) continue;
+    long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
+    long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+    if (area == 0) continue;
+    long long sg = area > 0 ? 1 : -1;
+    area *= sg;
+    long long xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+    long long ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+    long long ia = (xmin - 8 + 15) >> 4, ib = (xmax - 8) >> 4, ja = (ymin - 8 + 15) >> 4, jb = (ymax - 8) >> 4;
+    ia = max(ia, 0ll);
+    ja = max(ja, (long long)row0);
+    ib = min(ib, (long long)Wo - 1);
+    jb = min(jb, (long long)row1 - 1);
+    if (ia > ib || ja > jb) continue;
+    long long dx0 = sg * (X2 - X1), dy0 = sg * (Y2 - Y1);
+    long long dx1 = sg * (X0 - X2), dy1 = sg * (Y0 - Y2);
+    long long dx2 = sg * (X1 - X0), dy2 = sg * (Y1 - Y0);
+    bool tl0 = (dy0 > 0) || (dy0 == 0 && dx0 < 0);
+    bool tl1 = (dy1 > 0) || (dy1 == 0 && dx1 < 0);
+    bool tl2 = (dy2 > 0) || (dy2 == 0 && dx2 < 0);
+    float fa = (float)area;
+    for (long long j = ja; j <= jb; ++j) {
+      long long Py = 16 * j + 8;
+      for (long long i = ia; i <= ib; ++i) {
+        long long Px = 16 * i + 8;
+        long long e0 = dx0 * (Py - Y1) - dy0 * (Px - X1);
+        long long e1 = dx1 * (Py - Y2) - dy1 * (Px - X2);
+        long long e2 = dx2 * (Py - Y0) - dy2 * (Px - X0);
+        if (!((e0 > 0 || (e0 == 0 && tl0)) && (e1 > 0 || (e1 == 0 && tl1)) && (e2 > 0 || (e2 == 0 && tl2)))) continue;
+        float b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+        float zp = fmaf(b2, v2.zn, fmaf(b1, v1.zn, b0 * v0.zn));
+        if (!(zp >= -1.f && zp <= 1.f)) continue;
+        unsigned long long key = ((unsigned long long)ordered_key(zp) << 32) | (unsigned)t;
+        atomicMin(&zbuf[(int)(j - row0) * Wo + (int)i], key);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 2: per-pixel resolve + attribute interpolation + fused epilogue ----
+  const float P0 = sP[0], P1 = sP[1], P2 = sP[2], P3 = sP[3], P4 = sP[4], P5 = sP[5], P6 = sP[6], P7 = sP[7], P8 = sP[8],
+              P9 = sP[9], P10 = sP[10], P11 = sP[11];
+  for (int p = threadIdx.x; p < npix; p += RB_THREADS) {
+    const int jl = p / Wo, i = p - jl * Wo;
+    const int j = row0 + jl;
+    const int jo = Ho - 1 - j;  // flipped output row (src/Utils.py:216-218)
+    const size_t o = ((size_t)b * Ho + jo) * Wo + i;
+    unsigned long long key = zbuf[p];
+    float col[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, p3[3] = {0, 0, 0};
+    if (key != ~0ull) {
+      int t = (int)(unsigned)(key & 0xffffffffull);
+      int i0 = m.faces[t * 3], i1 = m.faces[t * 3 + 1], i2 = m.faces[t * 3 + 2];
+      Vtx v0 = xform_vertex(m.pos, i0, M, hw, hh);
+      Vtx v1 = xform_vertex(m.pos, i1, M, hw, hh);
+      Vtx v2 = xform_vertex(m.pos, i2, M, hw, hh);
+      long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
+      long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+      long long sg = area > 0 ? 1 : -1;
+      area *= sg;
+      long long Px = 16ll * i + 8, Py = 16ll * j + 8;
+      long long e0 = sg * ((X2 - X1) * (Py - Y1) - (Y2 - Y1) * (Px - X1));
+      long long e1 = sg * ((X0 - X2) * (Py - Y2) - (Y0 - Y2) * (Px - X2));
+      long long e2 = sg * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
+      float fa = (float)area;
+      float b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+      float q0 = b0 / v0.w, q1 = b1 / v1.w, q2 = b2 / v2.w;
+      float qs = (q0 + q1) + q2;
+      float u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
+      const int idx[3] = {i0, i1, i2};
+      float pc[3][3], nc[3][3], dv[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float px = m.pos[idx[k] * 3], py = m.pos[idx[k] * 3 + 1], pz = m.pos[idx[k] * 3 + 2];
+        pc[k][0] = fmaf(P0, px, fmaf(P1, py, fmaf(P2, pz, P3)));
+        pc[k][1] = fmaf(P4, px, fmaf(P5, py, fmaf(P6, pz, P7)));
+        pc[k][2] = fmaf(P8, px, fmaf(P9, py, fmaf(P10, pz, P11)));
+        float nx = m.vnormals[idx[k] * 3], ny = m.vnormals[idx[k] * 3 + 1], nz = m.vnormals[idx[k] * 3 + 2];
+        nc[k][0] = fmaf(P0, nx, fmaf(P1, ny, P2 * nz));
+        nc[k][1] = fmaf(P4, nx, fmaf(P5, ny, P6 * nz));
+        nc[k][2] = fmaf(P8, nx, fmaf(P9, ny, P10 * nz));
+        float nn = sqrtf(fmaf(nc[k][0], nc[k][0], fmaf(nc[k][1], nc[k][1], nc[k][2] * nc[k][2])));
+        nn = nn > 1e-12f ? nn : 1e-12f;
+        dv[k] = fminf(fmaxf(-(nc[k][2] / nn), 0.f), 1.f);
+      }
+      float base[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        p3[c] = fmaf(u, pc[0][c], fmaf(v, pc[1][c], w2 * pc[2][c]));
+        nrm[c] = fmaf(u, nc[0][c], fmaf(v, nc[1][c], w2 * nc[2][c]));
+      }
+      if (m.tex) {
+        int a0 = m.uv_idx[t * 3], a1 = m.uv_idx[t * 3 + 1], a2 = m.uv_idx[t * 3 + 2];
+        float tu = fmaf(u, m.uv[a0 * 2], fmaf(v, m.uv[a1 * 2], w2 * m.uv[a2 * 2]));
+        float tv = fmaf(u, m.uv[a0 * 2 + 1], fmaf(v, m.uv[a1 * 2 + 1], w2 * m.uv[a2 * 2 + 1]));
+        float x = tu * (float)m.texW - 0.5f, y = tv * (float)m.texH - 0.5f;
+        float fx0 = floorf(x), fy0 = floorf(y);
+        float fx = x - fx0, fy = y - fy0;
+        int x0 = (int)fx0 % m.texW;
+        if (x0 < 0) x0 += m.texW;
+        int y0 = (int)fy0 % m.texH;
+        if (y0 < 0) y0 += m.texH;
+        int x1 = (x0 + 1) % m.texW, y1 = (y0 + 1) % m.texH;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float t00 = m.tex[(y0 * m.texW + x0) * 3 + c], t10 = m.tex[(y0 * m.texW + x1) * 3 + c];
+          float t01 = m.tex[(y1 * m.texW + x0) * 3 + c], t11 = m.tex[(y1 * m.texW + x1) * 3 + c];
+          float ta = __fadd_rn(t00, __fmul_rn(fx, (t10 - t00)));
+          float tb = __fadd_rn(t01, __fmul_rn(fx, (t11 - t01)));
+          base[c] = __fadd_rn(ta, __fmul_rn(fy, (tb - ta)));
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          base[c] = fmaf(u, m.vcolor[i0 * 3 + c], fmaf(v, m.vcolor[i1 * 3 + c], w2 * m.vcolor[i2 * 3 + c]));
+      }
+      if (a.use_light) {
+        float d = fmaf(u, dv[0], fmaf(v, dv[1], w2 * dv[2]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          base[c] = __fadd_rn(__fmul_rn(base[c], a.w_ambient), __fmul_rn(__fmul_rn(d, base[c]), a.w_diffuse));
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[c] = fminf(fmaxf(base[c], 0.f), 1.f);
+      float nn = sqrtf(fmaf(nrm[0], nrm[0], fmaf(nrm[1], nrm[1], nrm[2] * nrm[2])));
+      nn = nn > 1e-12f ? nn : 1e-12f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nrm[c] = nrm[c] / nn;
+    }
+    if (MODE == 0) {
+      if (a.color) {
+        a.color[o * 3] = col[0];
+        a.color[o * 3 + 1] = col[1];
+        a.color[o * 3 + 2] = col[2];
+      }
+      if (a.normal) {
+        a.normal[o * 3] = nrm[0];
+        a.normal[o * 3 + 1] = nrm[1];
+        a.normal[o * 3 + 2] = nrm[2];
+      }
+      if (a.xyz) {
+        a.xyz[o * 3] = p3[0];
+        a.xyz[o * 3 + 1] = p3[1];
+        a.xyz[o * 3 + 2] = p3[2];
+      }
+      if (a.depth) a.depth[o] = p3[2];
+    } else {
+      // rgbAs = (color*255)/255 (predict_pose_refine.py:57 + h5_dataset.py:123); xyz transform h5_dataset.py:92-99 | 151-156
+      float r[6];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r[c] = __fdiv_rn(__fmul_rn(col[c], 255.f), 255.f);
+      bool invalid = p3[2] < a.invalid_thres;
+      float radius = __fdiv_rn(a.mesh_diameter, 2.f);
+      float inv_r = __fdiv_rn(1.f, radius);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float x = __fsub_rn(p3[c], pose[c * 4 + 3]);
+        if (a.normalize_xyz) {
+          x = __fmul_rn(x, inv_r);
+          if (invalid || fabsf(x) >= 2.f) x = 0.f;
+        }
+        r[3 + c] = x;
+      }
+      half8 hv;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) hv[c] = (f16)r[c];
+      hv[6] = (f16)0.f;
+      hv[7] = (f16)0.f;
+      *reinterpret_cast<half8 *>(a.net_out + o * 8) = hv;
+    }
+  }
+}
+
+int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s) {
+  FP_REQUIRE(a.N >= 0 && a.Ho > 0 && a.Wo > 0, "render: bad shape N=%d out=%dx%d", a.N, a.Ho, a.Wo);
+  if (a.N == 0) return FP_OK;
+  const size_t max_lds = 150 * 1024;
+  int strip_rows = (int)(max_lds / ((size_t)a.Wo * 8));
+  FP_REQUIRE(strip_rows >= 1, "render: output width %d too large for one LDS strip", a.Wo);
+  if (strip_rows > a.Ho) strip_rows = a.Ho;
+  int n_strips = (a.Ho + strip_rows - 1) / strip_rows;
+  strip_rows = (a.Ho + n_strips - 1) / n_strips;  // balance
+  size_t lds = (size_t)strip_rows * a.Wo * 8;
+  dim3 grid((unsigned)(a.N * n_strips));
+  ProfScope ps(ctx, s, "render", 0);
+  if (a.net_out) {
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)render_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(render_kernel<1>, grid, dim3(RB_THREADS), lds, s, a, strip_rows, n_strips);
+  } else {
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)render_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(render_kernel<0>, grid, dim3(RB_THREADS), lds, s, a, strip_rows, n_strips);
+  }
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// compute_crop_window_tf_batch(method='box_3d') (src/Utils.py:577-621) + bbox2d_ori
+// (predict_pose_refine.py:44-45).  float32, left-to-right, no FMA contraction: mirrors
+// oracle/geometry.py:compute_crop_window_tf_batch.
+// ----------------------------------------------------------------------------------------------
+__global__ void crop_window_tf_kernel(const float *__restrict__ poses, int N, float k00, float k01, float k02, float k10, float k11,
+                                      float k12, float k20, float k21, float k22, float radius, float ow, float oh, float *tf,
+                                      float *bbox) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= N) return;
+  const float *p = poses + (size_t)b * 16;
+  float tx = p[3], ty = p[7], tz = p[11];
+  float offx[5] = {0.f, radius, -radius, 0.f, 0.f};
+  float offy[5] = {0.f, 0.f, 0.f, radius, -radius};
+  float u[5], v[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    float x = __fadd_rn(tx, offx[k]), y = __fadd_rn(ty, offy[k]), z = __fadd_rn(tz, 0.f);
+    float pu = __fadd_rn(__fadd_rn(__fmul_rn(k00, x), __fmul_rn(k01, y)), __fmul_rn(k02, z));
+    float pv = __fadd_rn(__fadd_rn(__fmul_rn(k10, x), __fmul_rn(k11, y)), __fmul_rn(k12, z));
+    float pw = __fadd_rn(__fadd_rn(__fmul_rn(k20, x), __fmul_rn(k21, y)), __fmul_rn(k22, z));
+    u[k] = __fdiv_rn(pu, pw);
+    v[k] = __fdiv_rn(pv, pw);
+  }
+  float rad = 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    rad = fmaxf(rad, fabsf(__fsub_rn(u[k], u[0])));
+    rad = fmaxf(rad, fabsf(__fsub_rn(v[k], v[0])));
+  }
+  float left = rintf(__fsub_rn(u[0], rad)), right = rintf(__fadd_rn(u[0], rad));
+  float top = rintf(__fsub_rn(v[0], rad)), bottom = rintf(__fadd_rn(v[0], rad));
+  float sx = __fdiv_rn(ow, __fsub_rn(right, left)), sy = __fdiv_rn(oh, __fsub_rn(bottom, top));
+  float t02 = __fmul_rn(sx, -left), t12 = __fmul_rn(sy, -top);
+  float *T = tf + (size_t)b * 9;
+  T[0] = sx; T[1] = 0.f; T[2] = t02;
+  T[3] = 0.f; T[4] = sy; T[5] = t12;
+  T[6] = 0.f; T[7] = 0.f; T[8] = 1.f;
+  if (bbox) {
+    // tf^-1 applied to (0,0) and (ow-1,oh-1): inverse of [[sx,0,t02],[0,sy,t12],[0,0,1]]
+    float i00 = __fdiv_rn(1.f, sx), i11 = __fdiv_rn(1.f, sy);
+    float i02 = -__fdiv_rn(t02, sx), i12 = -__fdiv_rn(t12, sy);
+    float *B = bbox + (size_t)b * 4;
+    B[0] = i02;
+    B[1] = i12;
+    B[2] = __fadd_rn(__fmul_rn(i00, ow - 1.f), i02);
+    B[3] = __fadd_rn(__fmul_rn(i11, oh - 1.f), i12);
+  }
+}
+
+int launch_crop_window_tf(const float *poses, int N, const double *K, double crop_ratio, double diameter, int ow, int oh, float *tf,
+                          float *bbox, hipStream_t s) {
+  if (N == 0) return FP_OK;
+  float radius = (float)(diameter * crop_ratio / 2.0);
+  hipLaunchKernelGGL(crop_window_tf_kernel, dim3((N + 63) / 64), dim3(64), 0, s, poses, N, (float)K[0], (float)K[1], (float)K[2],
+                     (float)K[3], (float)K[4], (float)K[5], (float)K[6], (float)K[7], (float)K[8], radius, (float)ow, (float)oh, tf,
+                     bbox);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}

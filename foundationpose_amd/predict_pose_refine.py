@@ -1,0 +1,105 @@
+"""PoseRefinePredictor - mirror of learning/training/predict_pose_refine.py:94-296 on the HIP library.
+
+The whole refinement loop (crop window -> render -> observed crop -> RefineNet -> pose update, x
+`iteration`) runs on the device inside one C-ABI call (fp_refine_predict); poses never visit the
+host between iterations.
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FP_NET_REFINE, FpRefineCfg, byref, check, k_ptr, lib, ptr, stream_ptr
+from .Utils import RasterizeContext, _ctx_of, make_mesh_tensors
+from .config import Cfg, load_run_dir
+
+
+class PoseRefinePredictor:
+  run_name_default = "2023-10-28-18-33-37"      # predict_pose_refine.py:97
+
+  def __init__(self, state_dict=None, cfg=None, weights_root=None, device='cuda'):
+    """With no arguments: loads weights/<run_name>/{model_best.pth,config.yml} like the reference
+    (predict_pose_refine.py:94-141).  `state_dict` / `cfg` inject parameters directly (the weights
+    are not distributed with the repositories; tests and bench.py use seeded synthetic ones)."""
+    logging.info("welcome")
+    self.amp = True
+    self.run_name = self.run_name_default
+    if state_dict is None:
+      state_dict, file_cfg = load_run_dir(self.run_name, weights_root)
+      cfg = dict(file_cfg, **(cfg or {}))
+    self.cfg = Cfg(cfg or {})
+    self.cfg['enable_amp'] = True
+    ########## Defaults, to be backward compatible (predict_pose_refine.py:107-131)
+    defaults = dict(use_normal=False, use_mask=False, use_BN=False, c_in=4, n_view=1, trans_rep='tracknet', rot_rep='axis_angle',
+                    zfar=3, normalize_xyz=False, normal_uint8=False)
+    for k, v in defaults.items():
+      if k not in self.cfg:
+        self.cfg[k] = v
+    if 'crop_ratio' not in self.cfg or self.cfg['crop_ratio'] is None:
+      self.cfg['crop_ratio'] = 1.2
+    if isinstance(self.cfg['zfar'], str) and 'inf' in self.cfg['zfar'].lower():
+      self.cfg['zfar'] = np.inf
+    for k in ('input_resize', 'trans_normalizer', 'rot_normalizer'):
+      if k not in self.cfg:
+        raise KeyError(f"refiner config has no '{k}' (the reference reads it without a default)")
+    if tuple(self.cfg['input_resize']) != (160, 160):
+      raise NotImplementedError('the HIP networks are specialised for input_resize=(160,160)')
+    if self.cfg['use_normal']:
+      raise NotImplementedError('use_normal=True is not implemented (no released model uses it)')
+    self.device = torch.device(device)
+    self.ctx = _lib.Context.get(self.device)
+    self.model = _lib.DeviceNet(self.ctx, FP_NET_REFINE, state_dict, use_bn=bool(self.cfg['use_BN']))
+    want = 3 if self.cfg['rot_rep'] == 'axis_angle' else 6
+    if self.model.rot_dim != want:
+      raise RuntimeError(f"rot_rep={self.cfg['rot_rep']} needs a {want}-d rotation head, state_dict has {self.model.rot_dim}")
+    self.dataset = None
+    logging.info("init done")
+    self.last_trans_update = None
+    self.last_rot_update = None
+
+  @torch.inference_mode()
+  def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None, mesh_tensors=None, glctx=None,
+              mesh_diameter=None, iteration=5):
+    '''
+    @rgb: np array (H,W,3)
+    @ob_in_cams: np array (N,4,4)
+    returns (B_in_cams (N,4,4) float tensor on the device, vis or None)
+    '''
+    logging.info(f'ob_in_cams:{np.shape(ob_in_cams)}')
+    if self.cfg['trans_rep'] not in ('tracknet',) and self.cfg['trans_rep'] == 'deepim':
+      raise NotImplementedError("trans_rep='deepim' (non-default branch, predict_pose_refine.py:201-215) is not implemented")
+    if self.cfg['rot_rep'] not in ('axis_angle', '6d'):
+      raise RuntimeError
+    ctx = _ctx_of(glctx, self.device) if glctx is not None else self.ctx
+    dev = torch.device('cuda', ctx.device_index)
+    if mesh_tensors is None:
+      mesh_tensors = make_mesh_tensors(mesh, device=dev)
+    dm = _lib.device_mesh(ctx, mesh_tensors)
+    poses = torch.as_tensor(ob_in_cams, device=dev, dtype=torch.float).reshape(-1, 4, 4).contiguous().clone()
+    N = len(poses)
+    rgb_t = torch.as_tensor(rgb, device=dev, dtype=torch.float).contiguous()
+    xyz_t = torch.as_tensor(xyz_map, device=dev, dtype=torch.float).contiguous()
+    H, W = rgb_t.shape[:2]
+    assert xyz_t.shape[:2] == (H, W)
+    c = FpRefineCfg()
+    c.crop_ratio = float(self.cfg['crop_ratio'])
+    c.normalize_xyz = 1 if self.cfg['normalize_xyz'] else 0
+    tanh_branch = (self.cfg['trans_rep'] == 'tracknet') and not self.cfg['normalize_xyz']
+    c.trans_rep_tanh = 1 if tanh_branch else 0
+    tn = self.cfg['trans_normalizer']
+    tn = [float(tn)] * 3 if isinstance(tn, (float, int)) else [float(x) for x in tn]
+    for i in range(3):
+      c.trans_normalizer[i] = tn[i]
+    c.rot_normalizer = float(self.cfg['rot_normalizer'])
+    trans = torch.empty((N, 3), device=dev, dtype=torch.float)
+    rot = torch.empty((N, self.model.rot_dim), device=dev, dtype=torch.float)
+    Kd, Kp = k_ptr(K)
+    check(lib().fp_refine_predict(ctx.handle, self.model.handle, dm.handle, ptr(rgb_t), ptr(xyz_t), H, W, Kp, float(mesh_diameter),
+                                  byref(c), ptr(poses), N, int(iteration), ptr(trans), ptr(rot), stream_ptr(dev)))
+    self.last_trans_update = trans
+    self.last_rot_update = rot
+    if get_vis:
+      logging.info("get_vis: the debug canvas (cv2/torchvision drawing) is outside the hot path; returning None")
+    return poses, None

@@ -1,0 +1,93 @@
+"""ScorePredictor - mirror of learning/training/predict_score.py:118-226 on the HIP library."""
+import logging
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import FP_NET_SCORE, check, k_ptr, lib, ptr, stream_ptr
+from .Utils import _ctx_of, make_mesh_tensors
+from .config import Cfg, load_run_dir
+
+
+class ScorePredictor:
+  run_name_default = "2024-01-11-20-02-45"      # predict_score.py:120
+
+  def __init__(self, amp=True, state_dict=None, cfg=None, weights_root=None, device='cuda'):
+    self.amp = amp
+    self.run_name = self.run_name_default
+    if state_dict is None:
+      state_dict, file_cfg = load_run_dir(self.run_name, weights_root)
+      cfg = dict(file_cfg, **(cfg or {}))
+    self.cfg = Cfg(cfg or {})
+    self.cfg['enable_amp'] = True
+    ########## Defaults, to be backward compatible (predict_score.py:131-143)
+    defaults = dict(use_normal=False, use_BN=False, zfar=np.inf, c_in=4, normalize_xyz=False)
+    for k, v in defaults.items():
+      if k not in self.cfg:
+        self.cfg[k] = v
+    if 'crop_ratio' not in self.cfg or self.cfg['crop_ratio'] is None:
+      self.cfg['crop_ratio'] = 1.2
+    if 'input_resize' not in self.cfg:
+      raise KeyError("scorer config has no 'input_resize'")
+    if tuple(self.cfg['input_resize']) != (160, 160):
+      raise NotImplementedError('the HIP networks are specialised for input_resize=(160,160)')
+    if self.cfg['use_normal']:
+      raise NotImplementedError('use_normal=True is not implemented (no released model uses it)')
+    self.device = torch.device(device)
+    self.ctx = _lib.Context.get(self.device)
+    self.model = _lib.DeviceNet(self.ctx, FP_NET_SCORE, state_dict, use_bn=bool(self.cfg['use_BN']))
+    self.dataset = None
+    logging.info("init done")
+
+  @torch.inference_mode()
+  def extract_features(self, rgb, depth, K, ob_in_cams, mesh=None, mesh_tensors=None, glctx=None, mesh_diameter=None):
+    """Per-hypothesis part of predict (crop batch + ScoreNetMultiPair.extract_feat) -> (N,512) fp32.
+    This is the shardable half; `score_tail` couples the hypotheses."""
+    ctx = _ctx_of(glctx, self.device) if glctx is not None else self.ctx
+    dev = torch.device('cuda', ctx.device_index)
+    if mesh_tensors is None:
+      mesh_tensors = make_mesh_tensors(mesh, device=dev)
+    dm = _lib.device_mesh(ctx, mesh_tensors)
+    poses = torch.as_tensor(ob_in_cams, dtype=torch.float, device=dev).reshape(-1, 4, 4).contiguous()
+    rgb_t = torch.as_tensor(rgb, device=dev, dtype=torch.float).contiguous()
+    depth_t = torch.as_tensor(depth, device=dev, dtype=torch.float).contiguous()
+    H, W = depth_t.shape[:2]
+    N = len(poses)
+    feats = torch.empty((N, 512), dtype=torch.float, device=dev)
+    Kd, Kp = k_ptr(K)
+    check(lib().fp_score_predict_features(ctx.handle, self.model.handle, dm.handle, ptr(rgb_t), ptr(depth_t), H, W, Kp,
+                                          float(mesh_diameter), float(self.cfg['crop_ratio']), 1 if self.cfg['normalize_xyz'] else 0,
+                                          ptr(poses), N, ptr(feats), stream_ptr(dev)))
+    return feats
+
+  @torch.inference_mode()
+  def score_tail(self, feats, L=None):
+    """att_cross + linear over groups of L hypotheses (score_network.py:82-88): (groups*L,512) -> (groups,L)."""
+    feats = feats.contiguous()
+    M = feats.shape[0]
+    L = M if L is None else int(L)
+    assert M % L == 0
+    groups = M // L
+    logits = torch.empty((groups, L), dtype=torch.float, device=feats.device)
+    argmax = torch.empty((groups,), dtype=torch.int32, device=feats.device)
+    check(lib().fp_score_tail(self.ctx.handle, self.model.handle, ptr(feats), groups, L, ptr(logits), ptr(argmax), stream_ptr(feats.device)))
+    return logits, argmax
+
+  @torch.inference_mode()
+  def predict(self, rgb, depth, K, ob_in_cams, normal_map=None, get_vis=False, mesh=None, mesh_tensors=None, glctx=None,
+              mesh_diameter=None):
+    '''
+    @rgb: np array (H,W,3)
+    returns (scores (N,) float tensor on the device = logits + 100, vis or None)
+    '''
+    logging.info(f"ob_in_cams:{np.shape(ob_in_cams)}")
+    feats = self.extract_features(rgb, depth, K, ob_in_cams, mesh=mesh, mesh_tensors=mesh_tensors, glctx=glctx, mesh_diameter=mesh_diameter)
+    # find_best_among_pairs runs ONE forward over all hypotheses (bs == N), so the tournament loop of
+    # predict_score.py:206-212 exits in its first round: scores_global = logits + 100
+    logits, _ = self.score_tail(feats, L=len(feats))
+    scores = logits.reshape(-1) + 100
+    logging.info('forward done')
+    if get_vis:
+      logging.info("get_vis: the debug canvas is outside the hot path; returning None")
+    return scores, None

@@ -1,0 +1,164 @@
+/* foundationpose_amd - C ABI of the MI355X (gfx950) render-and-compare hot path.
+ *
+ * The reference (SavaRobotics/FoundationPose) has no FFI for this path: its boundary is a set of
+ * Python call signatures backed by third-party CUDA libraries.  Each entry point
+ * below names the reference interface it replaces (file:line relative to the reference repo).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative FP_E* code otherwise; fp_last_error() gives
+ *     the message of the last failure on the calling thread.
+ *   - `d_*` pointers are DEVICE pointers owned by the caller; `h_*` pointers are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Nothing synchronises
+ *     the stream except where stated; all launch functions are hipGraph-capturable.
+ *   - poses are row-major 4x4 float32 (ob_in_cam, OpenCV camera), K is row-major 3x3 float64.
+ *   - "net tensor" = fp16 NHWC with C padded to 8: [n][160][160][8] = (r,g,b,x,y,z,0,0), the
+ *     fused, network-ready form of the reference's (N,6,160,160) fp32 A/B tensors.
+ */
+#ifndef FOUNDATIONPOSE_AMD_H
+#define FOUNDATIONPOSE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FP_OK 0
+#define FP_EINVAL (-1)   /* bad argument / shape */
+#define FP_EHIP (-2)     /* HIP runtime error */
+#define FP_ENOMEM (-3)
+#define FP_EKEY (-4)     /* state_dict key missing / wrong shape */
+
+typedef struct fp_ctx fp_ctx;    /* per-device context: workspace arena (replaces dr.RasterizeCudaContext, src/estimater.py:102,168) */
+typedef struct fp_mesh fp_mesh;  /* device-resident mesh_tensors (src/Utils.py:104-130) */
+typedef struct fp_net fp_net;    /* folded + packed network weights (load_state_dict, predict_pose_refine.py:138-141 / predict_score.py:151-154) */
+
+const char *fp_last_error(void);
+int fp_version(void);
+
+/* ---- context ------------------------------------------------------------------------------- */
+int fp_ctx_create(int device, fp_ctx **out);
+int fp_ctx_destroy(fp_ctx *ctx);
+/* Pre-size the activation arena for batches of up to `max_hyp` hypotheses so that no allocation
+ * happens inside a timed / captured region. */
+int fp_ctx_reserve(fp_ctx *ctx, int max_hyp);
+
+/* ---- mesh: make_mesh_tensors (src/Utils.py:104-130); host pointers, copied to the device ---- */
+int fp_mesh_create(fp_ctx *ctx, const float *h_pos, int V, const int32_t *h_faces, int F, const float *h_vnormals,
+                   const float *h_vertex_color /* V*3 in [0,1] or NULL */,
+                   const float *h_uv /* n_uv*2, v already flipped, or NULL */, int n_uv, const int32_t *h_uv_idx /* F*3 */,
+                   const float *h_tex /* texH*texW*3 in [0,1] */, int texH, int texW, fp_mesh **out);
+int fp_mesh_destroy(fp_mesh *mesh);
+
+/* ---- a9: compute_crop_window_tf_batch(method='box_3d') (src/Utils.py:577-621) + bbox2d_ori
+ *      (predict_pose_refine.py:44-45).  d_tf: N*9, d_bbox2d: N*4 (umin,vmin,umax,vmax). -------- */
+int fp_crop_window_tf(fp_ctx *ctx, const float *d_poses, int N, const double *K, double crop_ratio, double mesh_diameter,
+                      int out_w, int out_h, float *d_tf, float *d_bbox2d, void *stream);
+
+/* ---- a11: nvdiffrast_render (src/Utils.py:133-219): fp32 channels-last maps, rows top-down,
+ *      background 0.  Any output pointer may be NULL.  d_bbox2d may be NULL (full frame). ------- */
+int fp_render(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+              const float *d_bbox2d, int out_h, int out_w, int use_light, float w_ambient, float w_diffuse,
+              float *d_color /* N*h*w*3 */, float *d_depth /* N*h*w */, float *d_normal /* N*h*w*3 */,
+              float *d_xyz /* N*h*w*3 */, void *stream);
+
+/* ---- a10/a13/a18 side A fused: render + rgb scaling + xyz centring / normalising / invalidating
+ *      (h5_dataset.py:92-99 | :151-156) straight into a net tensor.  invalid_thres = 0.001
+ *      (refiner) or 0.1 (scorer). ------------------------------------------------------------- */
+int fp_render_net(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+                  const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
+                  void *d_net_out /* fp16 N*h*w*8 */, void *stream);
+
+/* ---- a12/a13/a14 side B fused: kornia.warp_perspective crops of the observed frame + the batch
+ *      transform.  mode 0 = refiner (rgb bilinear + xyz_map nearest, predict_pose_refine.py:63,72;
+ *      h5_dataset.py:101-112); mode 1 = scorer (rgb bilinear + depth nearest + the full-resolution
+ *      depth->xyz round trip of h5_dataset.py:158-161, composed per pixel, never materialised).
+ *      d_rgb: H*W*3 float [0,255]; d_geom: H*W*3 xyz_map (mode 0) or H*W depth (mode 1).
+ *      out_fmt 0: fp32 planar N*6*h*w (the reference's cat([rgbB, xyz_mapB],1)); 1: fp16 net tensor. */
+int fp_crop_observed(fp_ctx *ctx, const float *d_rgb, const float *d_geom, int H, int W, const double *K,
+                     const float *d_tf, const float *d_poses, int N, int out_h, int out_w, int mode,
+                     double mesh_diameter, int normalize_xyz, int out_fmt, void *d_out, void *stream);
+
+/* ---- a6/a7/a8: depth pre-processing (src/Utils.py:304-438) ----------------------------------- */
+int fp_erode_depth(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
+                   float zfar, float *d_out, void *stream);
+int fp_bilateral_filter_depth(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float zfar, float sigmaD,
+                              float sigmaR, float *d_out, void *stream);
+int fp_depth2xyzmap(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float zfar, float *d_xyz, void *stream);
+
+/* ---- networks -------------------------------------------------------------------------------- */
+typedef struct {
+  const char *name;    /* reference state_dict key, e.g. "encodeA.0.net.0.weight" */
+  const float *data;   /* host fp32, contiguous */
+  int ndim;
+  int64_t shape[4];
+} fp_tensor;
+
+#define FP_NET_REFINE 0  /* RefineNet (learning/models/refine_network.py:27-93) */
+#define FP_NET_SCORE 1   /* ScoreNetMultiPair (learning/models/score_network.py:28-90) */
+/* Builds device weights from a reference-layout state_dict: BatchNorm (eval) folded into the
+ * preceding conv, fp16 [Cout][tap][Cin] packing, attention / linear weights.  use_bn mirrors cfg.use_BN. */
+int fp_net_create(fp_ctx *ctx, int kind, const fp_tensor *tensors, int n_tensors, int use_bn, fp_net **out);
+int fp_net_destroy(fp_net *net);
+int fp_net_rot_dim(const fp_net *net);   /* 3 (axis_angle) or 6 (6d), from rot_head.1.weight */
+
+/* a15: RefineNet.forward.  d_net_in: fp16 net tensor [2N][160][160][8], A = first N images, B = last N. */
+int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans /* N*3 */,
+                      float *d_rot /* N*rot_dim */, void *stream);
+/* a19: ScoreNetMultiPair.extract_feat -> d_feats N*512 fp32 */
+int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, void *stream);
+/* a19/a20: att_cross + linear over `groups` objects of L hypotheses each (score_network.py:82-88),
+ * logits groups*L; d_argmax (groups, may be NULL) = per-object argmax (predict_score.py:196). */
+int fp_score_tail(fp_ctx *ctx, const fp_net *net, const float *d_feats, int groups, int L, float *d_logits,
+                  int32_t *d_argmax, void *stream);
+
+/* a16: pose update (predict_pose_refine.py:195-231 + so3_exp_map + egocentric_delta_pose_to_pose).
+ * trans_rep_tanh: 1 -> tanh(trans)*trans_normalizer (normalize_xyz False), 0 -> raw.  rot_dim 3|6. */
+int fp_pose_update(fp_ctx *ctx, const float *d_poseA, const float *d_trans, const float *d_rot, int N, int rot_dim,
+                   int trans_rep_tanh, const float *trans_normalizer3, float rot_normalizer, float trans_scale,
+                   float *d_pose_out, void *stream);
+
+/* a17: PoseRefinePredictor.predict inner loop (predict_pose_refine.py:182-234), `iteration` rounds of
+ * crop-window -> render -> observed crop -> RefineNet -> pose update, entirely on the device.
+ * d_poses is updated in place.  d_trans/d_rot (may be NULL) receive the last raw network outputs. */
+typedef struct {
+  double crop_ratio;
+  int normalize_xyz;
+  int trans_rep_tanh;
+  float trans_normalizer[3];
+  float rot_normalizer;
+} fp_refine_cfg;
+int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_xyz_map,
+                      int H, int W, const double *K, double mesh_diameter, const fp_refine_cfg *cfg, float *d_poses, int N,
+                      int iteration, float *d_trans, float *d_rot, void *stream);
+
+/* a18-a20: ScorePredictor.predict up to per-hypothesis features (shardable), then the tail. */
+int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_depth,
+                              int H, int W, const double *K, double mesh_diameter, double crop_ratio, int normalize_xyz,
+                              const float *d_poses, int N, float *d_feats, void *stream);
+
+/* ---- building blocks exported for parity tests and profiling ---------------------------------- */
+/* fp16 NHWC implicit-GEMM convolution on MFMA: out = act(conv(in, w) + bias [+ res]).  w_packed is
+ * [Cout][Kpad] fp16 with k = (ky*KW+kx)*Cin + ci, Kpad = roundup(KH*KW*Cin, 32), zero padded. */
+int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin, const void *d_w_packed, const float *d_bias,
+                  int Cout, int KH, int KW, int stride, int pad, const void *d_res, int relu, void *d_out, int out_f32,
+                  void *stream);
+/* fused multi-head self-attention core, 4 heads x 128: qk [M][1024] fp16 (q|k), vt [B][4][128][416] fp16 -> out [M][512] fp16 */
+int fp_attention_f16(fp_ctx *ctx, const void *d_qk, const void *d_vt, int B, int T, void *d_out, void *stream);
+
+/* mycpp.cluster_poses (mycpp/src/app/pybind_api.cpp:24-68); host function, float32 row-major 4x4.
+ * h_out must hold n_in*16 floats; returns the number of kept poses (>=1) or a negative error. */
+int fp_cluster_poses(float angle_diff_deg, float dist_diff_m, const float *h_poses_in, int n_in, const float *h_symmetry_tfs,
+                     int n_sym, float *h_out);
+
+/* timing helper: average device time (ms) of the dominant conv kernel class over the launches since
+ * the last reset, measured with HIP events on the launch stream when profiling is enabled. */
+int fp_prof_enable(fp_ctx *ctx, int on);
+int fp_prof_read(fp_ctx *ctx, const char *kernel_class, double *total_ms, int64_t *launches, double *flops);
+int fp_prof_reset(fp_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

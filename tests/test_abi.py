@@ -1,0 +1,51 @@
+"""CPU: the built C-ABI library loads and exports every symbol include/foundationpose_amd.h declares
+(no compute calls - there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def header_symbols():
+  src = open(os.path.join(REPO, 'include', 'foundationpose_amd.h')).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  return sorted(set(re.findall(r'\b(fp_[a-z0-9_]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def built():
+  import __graft_entry__ as g
+  g.build()
+  from foundationpose_amd import _lib
+  return _lib
+
+
+def test_header_and_binding_agree(built):
+  assert header_symbols() == built.exported_symbols()
+
+
+def test_library_exports_every_symbol(built):
+  L = ctypes.CDLL(built.LIB_PATH)
+  for s in header_symbols():
+    assert hasattr(L, s), f'{s} missing from libfoundationpose_amd.so'
+  assert built.lib().fp_version() >= 100
+
+
+def test_product_does_not_import_oracle():
+  """The product path must never route through the CPU oracle."""
+  pkg = os.path.join(REPO, 'foundationpose_amd')
+  for root, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(('.py', '.hip', '.h', '.cpp')):
+        txt = open(os.path.join(root, f)).read()
+        assert 'import oracle' not in txt and 'from oracle' not in txt, f'{f} references the oracle'
+
+
+def test_missing_library_fails_loudly(monkeypatch, built):
+  monkeypatch.setattr(built, '_lib', None)
+  monkeypatch.setattr(built, 'LIB_PATH', '/nonexistent/libfoundationpose_amd.so')
+  with pytest.raises(built.FoundationPoseAmdError):
+    built.lib()

@@ -1,0 +1,281 @@
+"""GPU parity: each HIP kernel, called through the C-ABI, against the CPU oracle on the same seeded
+inputs (sizes the oracle finishes in seconds).  Tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def sc():
+  return util.scene(0)
+
+
+@pytest.fixture(scope='module')
+def fp():
+  from foundationpose_amd import Utils, _lib
+  return dict(U=Utils, L=_lib, ctx=_lib.Context.get('cuda:0'))
+
+
+def test_crop_window_tf(sc, fp):
+  from oracle import geometry as G
+  poses = util.hypotheses(sc, 64, jitter_seed=3)
+  for ratio in (1.2, 1.1):
+    tf_o = G.compute_crop_window_tf_batch(torch.from_numpy(poses), sc['K'], ratio, (160, 160), sc['diameter'])
+    tf_g = fp['U'].compute_crop_window_tf_batch(poses=poses, K=sc['K'], crop_ratio=ratio, out_size=(160, 160), method='box_3d',
+                                                mesh_diameter=sc['diameter'])
+    # same float32 op order on both sides -> bit-exact
+    np.testing.assert_array_equal(tf_g.cpu().numpy(), tf_o.numpy())
+  with pytest.raises(RuntimeError):
+    fp['U'].compute_crop_window_tf_batch(poses=poses, K=sc['K'], method='min_box', mesh_diameter=0.1, out_size=(160, 160))
+
+
+def _render_pair(sc, fp, poses, bbox, out, mt_cpu=None, use_light=True):
+  from oracle.render import nvdiffrast_render as orender
+  mt_cpu = mt_cpu or sc['mt']
+  eo, eg = {}, {}
+  co, do, no = orender(K=sc['K'], H=480, W=640, ob_in_cams=poses, mesh_tensors=mt_cpu, bbox2d=bbox, output_size=out,
+                       use_light=use_light, get_normal=True, extra=eo)
+  cg, dg, ng = fp['U'].nvdiffrast_render(K=sc['K'], H=480, W=640, ob_in_cams=torch.from_numpy(poses).cuda(),
+                                         mesh_tensors=util.to_dev(mt_cpu), bbox2d=None if bbox is None else bbox.cuda(),
+                                         output_size=out, use_light=use_light, get_normal=True, extra=eg)
+  return (co, do, no, eo['xyz_map']), (cg.cpu(), dg.cpu(), ng.cpu(), eg['xyz_map'].cpu())
+
+
+@pytest.mark.parametrize('textured', [False, True])
+def test_render_crops_match_oracle(sc, fp, textured):
+  """Rasteriser: coverage is decided in integer arithmetic -> identical pixel sets; interpolants are the
+  same fmaf chains -> agree to float32 rounding (1e-6 abs on values <= 1).  Allowance: 1e-4 of the
+  pixels may differ (a 1-ulp difference in a snapped vertex flips an edge pixel)."""
+  from oracle import geometry as G
+  s = util.scene(0, textured=textured) if textured else sc
+  poses = util.hypotheses(s, 12, jitter_seed=5)
+  tf = G.compute_crop_window_tf_batch(torch.from_numpy(poses), s['K'], 1.2, (160, 160), s['diameter'])
+  bbox = G.crop_bbox2d_ori(tf, (160, 160))
+  ref, got = _render_pair(s, fp, poses, bbox, (160, 160), mt_cpu=s['mt'])
+  cov_o, cov_g = ref[1] > 0, got[1] > 0
+  assert float((cov_o != cov_g).float().mean()) <= 1e-4
+  assert float(cov_o.float().mean()) > 0.15          # the object fills a good part of the crop
+  for name, a, b in zip(('color', 'depth', 'normal', 'xyz'), ref, got):
+    frac, mx, med = util.mismatch_report(a.numpy(), b.numpy(), 2e-6)
+    assert frac <= 2e-4, f'{name}: {frac:.2e} of values differ by > 2e-6 (max {mx:.2e})'
+
+
+def test_render_full_frame_and_edge_cases(sc, fp):
+  poses = util.hypotheses(sc, 2)
+  poses[1, :3, 3] = [5.0, 5.0, 1.0]      # entirely outside the frustum -> empty image
+  ref, got = _render_pair(sc, fp, poses, None, (480, 640))
+  assert float((ref[1] > 0).float().sum()) > 1000
+  for a, b in zip(ref, got):
+    frac, mx, _ = util.mismatch_report(a.numpy(), b.numpy(), 2e-6)
+    assert frac <= 2e-4
+  assert float(got[1][1].abs().max()) == 0.0
+  # object behind the camera: w <= 0 culls everything
+  poses[0, 2, 3] = -0.5
+  _, got = _render_pair(sc, fp, poses[:1], None, (64, 64))
+  assert float(got[1].abs().max()) == 0.0
+  # zero hypotheses
+  c, d, n = fp['U'].nvdiffrast_render(K=sc['K'], H=480, W=640, ob_in_cams=torch.zeros((0, 4, 4)).cuda(), mesh_tensors=util.to_dev(sc['mt']),
+                                      output_size=(160, 160))
+  assert c.shape == (0, 160, 160, 3)
+  with pytest.raises(NotImplementedError):
+    fp['U'].nvdiffrast_render(K=sc['K'], H=480, W=640, ob_in_cams=torch.from_numpy(poses).cuda(), mesh_tensors=util.to_dev(sc['mt']),
+                              context='metal', glctx=None)
+
+
+def _net_tensor_to_planar(t, n):
+  """fp16 NHWC8 net tensor -> (n,6,160,160) float32"""
+  return t.reshape(n, 160, 160, 8)[..., :6].permute(0, 3, 1, 2).float().cpu()
+
+
+@pytest.mark.parametrize('which', ['refine', 'score'])
+def test_fused_crop_tensors_match_oracle(sc, fp, which):
+  """A (render) and B (observed crop) network inputs, fused kernels vs the oracle's
+  make_crop_data_batch.  fp16 storage: |err| <= 2^-11 relative (values <= 2) -> atol 1.5e-3; nearest-
+  sampled channels may pick a neighbouring source pixel when the coordinate is within 1e-5 of .5
+  (allowance 5e-4 of the pixels)."""
+  from oracle import predict as OP
+  from foundationpose_amd._lib import check, k_ptr, lib, ptr, stream_ptr
+  L, ctx = fp['L'], fp['ctx']
+  n = 8
+  poses = util.hypotheses(sc, n, jitter_seed=7)
+  from oracle import geometry as G
+  depth = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+  rgb_t = torch.as_tensor(sc['rgb'], dtype=torch.float32)
+  if which == 'refine':
+    cfg = dict(OP.DEFAULT_REFINE_CFG)
+    xyz_map = torch.from_numpy(G.depth2xyzmap(depth, sc['K']))
+    pd = OP.make_crop_data_batch_refine(cfg, poses, sc['mt'], rgb_t, torch.from_numpy(depth), sc['K'], xyz_map, sc['diameter'])
+    geom, mode, thres = xyz_map.cuda().contiguous(), 0, 0.001
+  else:
+    cfg = dict(OP.DEFAULT_SCORE_CFG)
+    pd = OP.make_crop_data_batch_score(cfg, poses, sc['mt'], rgb_t, torch.from_numpy(depth), sc['K'], sc['diameter'])
+    geom, mode, thres = torch.from_numpy(depth).cuda().contiguous(), 1, 0.1
+  A_ref = torch.cat([pd['rgbAs'], pd['xyz_mapAs']], 1)
+  B_ref = torch.cat([pd['rgbBs'], pd['xyz_mapBs']], 1)
+  dposes = torch.from_numpy(poses).cuda()
+  tf = torch.empty((n, 3, 3), device='cuda')
+  bbox = torch.empty((n, 4), device='cuda')
+  Kd, Kp = k_ptr(sc['K'])
+  s = stream_ptr()
+  check(lib().fp_crop_window_tf(ctx.handle, ptr(dposes), n, Kp, cfg['crop_ratio'], sc['diameter'], 160, 160, ptr(tf), ptr(bbox), s))
+  np.testing.assert_array_equal(tf.cpu().numpy(), pd['tf_to_crops'].numpy())
+  net = torch.zeros((2 * n, 160, 160, 8), dtype=torch.float16, device='cuda')
+  dm = L.device_mesh(ctx, util.to_dev(sc['mt']))
+  check(lib().fp_render_net(ctx.handle, dm.handle, ptr(dposes), n, Kp, 480, 640, ptr(bbox), 160, 160, sc['diameter'], 1, thres, ptr(net), s))
+  rgb_d = rgb_t.cuda().contiguous()
+  check(lib().fp_crop_observed(ctx.handle, ptr(rgb_d), ptr(geom), 480, 640, Kp, ptr(tf), ptr(dposes), n, 160, 160, mode, sc['diameter'], 1, 1,
+                               ptr(net[n:]), s))
+  Bf32 = torch.empty((n, 6, 160, 160), device='cuda')
+  check(lib().fp_crop_observed(ctx.handle, ptr(rgb_d), ptr(geom), 480, 640, Kp, ptr(tf), ptr(dposes), n, 160, 160, mode, sc['diameter'], 1, 0,
+                               ptr(Bf32), s))
+  torch.cuda.synchronize()
+  A_g, B_g = _net_tensor_to_planar(net[:n], n), _net_tensor_to_planar(net[n:], n)
+  assert float(net[..., 6:].abs().max()) == 0.0
+  fa, ma, _ = util.mismatch_report(A_ref.numpy(), A_g.numpy(), 1.5e-3)
+  assert fa <= 2e-4, f'A: {fa:.2e} mismatching (max {ma:.3f})'
+  # B, float32 output: rgb (bilinear) tight, xyz (nearest) with the boundary allowance
+  f_rgb, m_rgb, _ = util.mismatch_report(B_ref[:, :3].numpy(), Bf32[:, :3].cpu().numpy(), 2e-5)
+  assert f_rgb <= 1e-4, f'rgbB: {f_rgb:.2e} (max {m_rgb:.2e})'
+  f_xyz, m_xyz, _ = util.mismatch_report(B_ref[:, 3:].numpy(), Bf32[:, 3:].cpu().numpy(), 1e-5)
+  assert f_xyz <= 5e-4, f'xyzB: {f_xyz:.2e} (max {m_xyz:.2e})'
+  fb, mb, _ = util.mismatch_report(B_ref.numpy(), B_g.numpy(), 1.5e-3)
+  assert fb <= 5e-4
+  assert float((B_ref[:, 3:] != 0).float().mean()) > 0.05     # the observed object is inside the crops
+
+
+def test_depth_filters(sc, fp):
+  from oracle import geometry as G
+  U = fp['U']
+  d = sc['depth'].copy()
+  d[100:104, 200:260] = 150.0          # beyond zfar
+  e_o = G.erode_depth(d, radius=2)
+  e_g = U.erode_depth(d, radius=2, device='cuda')
+  assert isinstance(e_g, np.ndarray)
+  np.testing.assert_array_equal(e_g, e_o)
+  b_o = G.bilateral_filter_depth(e_o, radius=2)
+  b_g = U.bilateral_filter_depth(e_o, radius=2, device='cuda')
+  np.testing.assert_allclose(b_g, b_o, atol=2e-6, rtol=0)      # expf vs np.exp: <= 2 ulp on O(1) metres
+  # tensor in -> tensor out (src/Utils.py:353-355,393-394)
+  assert torch.is_tensor(U.erode_depth(torch.from_numpy(d).cuda(), radius=2))
+  xb_o = G.depth2xyzmap_batch(torch.from_numpy(b_o)[None], torch.as_tensor(sc['K'], dtype=torch.float32)[None], zfar=np.inf)
+  xb_g = U.depth2xyzmap_batch(torch.from_numpy(b_o)[None].cuda(), torch.as_tensor(sc['K'], dtype=torch.float32)[None], zfar=np.inf)
+  np.testing.assert_allclose(xb_g.cpu().numpy(), xb_o.numpy(), atol=1e-6)
+  # all-invalid and tiny images
+  z = np.zeros((5, 7), np.float32)
+  assert U.erode_depth(z, radius=2).max() == 0 and U.bilateral_filter_depth(z, radius=2).max() == 0
+
+
+def test_pose_update(fp):
+  from oracle import predict as OP
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  rs = np.random.RandomState(3)
+  n = 37
+  A = np.tile(np.eye(4, dtype=np.float32), (n, 1, 1))
+  from foundationpose_amd.synthetic import random_rotation
+  for i in range(n):
+    A[i, :3, :3] = random_rotation(rs)
+  A[:, :3, 3] = rs.randn(n, 3) * 0.3
+  trans = (rs.randn(n, 3) * 0.5).astype(np.float32)
+  trans[0] = 0
+  for rot_dim, rep in ((3, 'axis_angle'), (6, '6d')):
+    rot = (rs.randn(n, rot_dim) * 0.7).astype(np.float32)
+    if rot_dim == 3:
+      rot[0] = 0          # exercises the eps clamp of so3_exp_map
+    for norm_xyz in (True, False):
+      cfg = dict(OP.DEFAULT_REFINE_CFG, rot_rep=rep, normalize_xyz=norm_xyz)
+      ref, _, _ = OP.pose_update(cfg, torch.from_numpy(A), torch.from_numpy(trans), torch.from_numpy(rot), 0.191)
+      out = torch.empty((n, 4, 4), device='cuda')
+      tn = np.asarray(cfg['trans_normalizer'], dtype=np.float32)
+      check(lib().fp_pose_update(fp['ctx'].handle, ptr(torch.from_numpy(A).cuda()), ptr(torch.from_numpy(trans).cuda()),
+                                 ptr(torch.from_numpy(rot).cuda()), n, rot_dim, 0 if norm_xyz else 1, ptr(tn), cfg['rot_normalizer'],
+                                 np.float32(0.191 / 2) if norm_xyz else 1.0, ptr(out), stream_ptr()))
+      np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-6)
+
+
+def _pack_conv_weight(w, cin_pad):
+  cout, cin, k, _ = w.shape
+  kraw = k * k * cin_pad
+  kpad = (kraw + 31) // 32 * 32
+  p = torch.zeros((cout, kpad), dtype=torch.float16)
+  wp = torch.zeros((cout, k, k, cin_pad))
+  wp[..., :cin] = w.permute(0, 2, 3, 1)
+  p[:, :kraw] = wp.reshape(cout, -1).half()
+  return p
+
+
+@pytest.mark.parametrize('shape', [
+  # (N, H, W, Cin, Cout, k, stride, residual, relu)
+  (3, 40, 40, 128, 128, 3, 1, True, True),
+  (2, 40, 40, 256, 256, 3, 1, False, True),
+  (2, 80, 80, 64, 128, 3, 2, False, True),
+  (3, 20, 20, 512, 512, 3, 1, True, True),
+  (2, 40, 40, 256, 512, 3, 2, False, True),
+  (2, 160, 160, 6, 64, 7, 2, False, True),
+  (1, 1, 1000, 512, 1024, 1, 1, False, False),     # a Linear layer (1x1, M=1000 tokens: ragged last tile)
+  (1, 1, 130, 512, 64, 1, 1, False, False),
+])
+def test_conv_igemm_vs_fp32_reference(fp, shape):
+  """MFMA implicit GEMM vs torch fp32 conv2d on the same fp16-rounded operands; fp32 accumulate ->
+  the only error is accumulation order + the fp16 output rounding: rtol 2e-3 of the output scale."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  N, H, W, Cin, Cout, k, stride, use_res, relu = shape
+  g = torch.Generator().manual_seed(sum(shape))
+  x = torch.randn((N, Cin, H, W), generator=g).half()
+  w = (torch.randn((Cout, Cin, k, k), generator=g) * (2.0 / (Cin * k * k)) ** 0.5).half()
+  b = torch.randn((Cout,), generator=g) * 0.1
+  pad = (k - 1) // 2
+  ref = torch.nn.functional.conv2d(x.float(), w.float(), b, stride=stride, padding=pad)
+  cin_pad = 8 if Cin < 8 else Cin
+  xin = torch.zeros((N, H, W, cin_pad), dtype=torch.float16)
+  xin[..., :Cin] = x.permute(0, 2, 3, 1)
+  res = None
+  if use_res:
+    res = torch.randn(ref.shape, generator=g).half()
+    ref = ref + res.float()
+    res_d = res.permute(0, 2, 3, 1).contiguous().cuda()
+  if relu:
+    ref = torch.relu(ref)
+  wp = _pack_conv_weight(w.float(), cin_pad).cuda()
+  Ho, Wo = ref.shape[-2:]
+  for out_f32 in (0, 1):
+    out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else torch.float16, device='cuda')
+    check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(xin.cuda()), N, H, W, cin_pad, ptr(wp), ptr(b.cuda()), Cout, k, k, stride, pad,
+                              ptr(res_d) if use_res else None, 1 if relu else 0, ptr(out), out_f32, stream_ptr()))
+    got = out.float().permute(0, 3, 1, 2).cpu()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err <= (2e-3 if not out_f32 else 2e-4) * scale + 1e-5, f'out_f32={out_f32}: err {err:.3e} scale {scale:.2f}'
+
+
+def test_conv_rejects_bad_shapes(fp):
+  from foundationpose_amd._lib import FoundationPoseAmdError, check, lib, ptr, stream_ptr
+  x = torch.zeros((1, 4, 4, 48), dtype=torch.float16, device='cuda')
+  w = torch.zeros((64, 448), dtype=torch.float16, device='cuda')
+  b = torch.zeros((64,), device='cuda')
+  o = torch.zeros((1, 4, 4, 64), dtype=torch.float16, device='cuda')
+  with pytest.raises(FoundationPoseAmdError):
+    check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(x), 1, 4, 4, 48, ptr(w), ptr(b), 64, 3, 3, 1, 1, None, 1, ptr(o), 0, stream_ptr()))
+
+
+def test_attention_vs_reference(fp):
+  """Fused MHA core vs softmax(QK^T/sqrt(128))V in fp32 on the same fp16 operands.  P is rounded to
+  fp16 before the PV MFMA: |err| <= 2^-11 * sum|p v| -> atol 2e-3 on O(1) values."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  g = torch.Generator().manual_seed(5)
+  B, T = 3, 400
+  qk = (torch.randn((B * T, 1024), generator=g) * 1.5).half()
+  v = torch.randn((B * T, 512), generator=g).half()
+  vt = torch.zeros((B, 4, 128, 416), dtype=torch.float16)
+  vt[..., :T] = v.reshape(B, T, 4, 128).permute(0, 2, 3, 1)
+  out = torch.empty((B * T, 512), dtype=torch.float16, device='cuda')
+  check(lib().fp_attention_f16(fp['ctx'].handle, ptr(qk.cuda()), ptr(vt.cuda()), B, T, ptr(out), stream_ptr()))
+  q = qk[:, :512].float().reshape(B, T, 4, 128).transpose(1, 2)
+  k = qk[:, 512:].float().reshape(B, T, 4, 128).transpose(1, 2)
+  vv = v.float().reshape(B, T, 4, 128).transpose(1, 2)
+  ref = (torch.softmax(q @ k.transpose(-1, -2) / 128 ** 0.5, -1) @ vv).transpose(1, 2).reshape(B * T, 512)
+  err = float((out.float().cpu() - ref).abs().max())
+  assert err <= 2e-3, err
