@@ -210,7 +210,7 @@ extern "C" int fp_crop_window_tf(fp_ctx *ctx, const float *d_poses, int N, const
 
 static int fill_render(RenderArgs &a, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
                        const float *d_bbox2d, int out_h, int out_w) {
-  FP_REQUIRE(mesh && d_poses && K, "render: null argument");
+  FP_REQUIRE(mesh && K && (d_poses || N == 0), "render: null argument");
   FP_REQUIRE(N >= 0 && H > 0 && W > 0 && out_h > 0 && out_w > 0, "render: bad shape");
   memset(&a, 0, sizeof(a));
   a.mesh = mesh->d;

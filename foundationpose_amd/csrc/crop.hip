@@ -5,11 +5,22 @@
 // kornia 0.7.2's map (normalise with (size-1), invert, grid_sample(align_corners=False)) collapses,
 // for the axis-aligned crop transform tf = [[sx,0,tx],[0,sy,ty],[0,0,1]], to
 //     x_src = ((i - tx)/sx) * W/(W-1) - 0.5,   y_src = ((j - ty)/sy) * H/(H-1) - 0.5
-// evaluated here in float64 per pixel and rounded once to float32 (oracle/warp.py restates the
-// literal float32 chain; the two agree except where x_src is within ~1e-5 of a rounding boundary).
+// evaluated here in float64 per pixel (bilinear taps then use the float32-rounded coordinate, as
+// F.grid_sample does; nearest lookups use round_snapped below).
 // The frame (480x640x(3+3) floats = 7 MB) is L2/MALL resident; every hypothesis re-reads it from
 // cache and the only HBM traffic is the 16 B/pixel network-ready store.
 #include "common.h"
+
+// nearbyint in float64 with coordinates within 1e-4 px of a half-integer treated as exact ties
+// (round half to even) - same rule as oracle/warp.py:round_half_even_snapped, which explains why.
+__device__ __forceinline__ int round_snapped(double x) {
+  double f = floor(x), t = x - f;
+  if (fabs(t - 0.5) < 1e-4) {
+    long long fi = (long long)f;
+    return (int)((fi & 1) ? fi + 1 : fi);
+  }
+  return (int)floor(x + 0.5);
+}
 
 __device__ __forceinline__ float frame_at(const float *img, int H, int W, int C, int y, int x, int c) {
   return (y >= 0 && y < H && x >= 0 && x < W) ? img[((size_t)y * W + x) * C + c] : 0.f;
@@ -26,7 +37,8 @@ __global__ __launch_bounds__(256) void crop_observed_kernel(CropArgs a) {
   const int H = a.H, W = a.W;
   const double ax = (1.0 / sx) * W / (W - 1.0), bx = (-tx / sx) * W / (W - 1.0) - 0.5;
   const double ay = (1.0 / sy) * H / (H - 1.0), by = (-ty / sy) * H / (H - 1.0) - 0.5;
-  const float x = (float)(ax * i + bx), y = (float)(ay * j + by);
+  const double xd = ax * i + bx, yd = ay * j + by;
+  const float x = (float)xd, y = (float)yd;
 
   // ---- rgb: bilinear, zeros padding (F.grid_sample arithmetic, float32) ----
   float rgb[3];
@@ -46,7 +58,7 @@ __global__ __launch_bounds__(256) void crop_observed_kernel(CropArgs a) {
     }
   }
   // ---- geometry: nearest (round half to even), zeros padding ----
-  const int qx = (int)rintf(x), qy = (int)rintf(y);
+  const int qx = round_snapped(xd), qy = round_snapped(yd);
   const bool q_in = (qx >= 0 && qx < W && qy >= 0 && qy < H);
   float xyz[3] = {0.f, 0.f, 0.f};
   float invalid_thres;
@@ -64,11 +76,10 @@ __global__ __launch_bounds__(256) void crop_observed_kernel(CropArgs a) {
       //   p~ = tf * q ;  x' = p~ * Wo/(Wo-1) - 0.5
       const double cxp = (sx * qx + tx) * a.Wo / (a.Wo - 1.0) - 0.5;
       const double cyp = (sy * qy + ty) * a.Ho / (a.Ho - 1.0) - 0.5;
-      const int pi = (int)rintf((float)cxp), pj = (int)rintf((float)cyp);
+      const int pi = round_snapped(cxp), pj = round_snapped(cyp);
       float z = 0.f;
       if (pi >= 0 && pi < a.Wo && pj >= 0 && pj < a.Ho) {
-        const float x2 = (float)(ax * pi + bx), y2 = (float)(ay * pj + by);
-        const int rx = (int)rintf(x2), ry = (int)rintf(y2);
+        const int rx = round_snapped(ax * pi + bx), ry = round_snapped(ay * pj + by);
         if (rx >= 0 && rx < W && ry >= 0 && ry < H) z = a.geom[(size_t)ry * W + rx];
       }
       // depth2xyzmap_batch (src/Utils.py:420-438), zfar = inf, float32

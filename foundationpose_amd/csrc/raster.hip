@@ -341,7 +341,8 @@ __global__ void crop_window_tf_kernel(const float *__restrict__ poses, int N, fl
   }
   float left = rintf(__fsub_rn(u[0], rad)), right = rintf(__fadd_rn(u[0], rad));
   float top = rintf(__fsub_rn(v[0], rad)), bottom = rintf(__fadd_rn(v[0], rad));
-  float sx = __fdiv_rn(ow, __fsub_rn(right, left)), sy = __fdiv_rn(oh, __fsub_rn(bottom, top));
+  // `out_size[0]/(right-left)` is int / Tensor in the reference -> Tensor.__rtruediv__ = reciprocal() * scalar
+  float sx = __fmul_rn(__fdiv_rn(1.f, __fsub_rn(right, left)), ow), sy = __fmul_rn(__fdiv_rn(1.f, __fsub_rn(bottom, top)), oh);
   float t02 = __fmul_rn(sx, -left), t12 = __fmul_rn(sy, -top);
   float *T = tf + (size_t)b * 9;
   T[0] = sx; T[1] = 0.f; T[2] = t02;

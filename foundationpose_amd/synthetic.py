@@ -188,9 +188,11 @@ def _linear(rs, sd, name, cout, cin, gain=1.0):
   sd[f'{name}.bias'] = torch.from_numpy(rs.uniform(-bound, bound, cout).astype(np.float32))
 
 
-def _mha(rs, sd, name, d=512):
+def _mha(rs, sd, name, d=512, qk_gain=1.0):
   bound = math.sqrt(6.0 / (d + 3 * d))
-  sd[f'{name}.in_proj_weight'] = torch.from_numpy(rs.uniform(-bound, bound, (3 * d, d)).astype(np.float32))
+  w = rs.uniform(-bound, bound, (3 * d, d)).astype(np.float32)
+  w[:2 * d] *= qk_gain
+  sd[f'{name}.in_proj_weight'] = torch.from_numpy(w)
   sd[f'{name}.in_proj_bias'] = torch.from_numpy((rs.randn(3 * d) * 0.02).astype(np.float32))
   _linear(rs, sd, f'{name}.out_proj', d, d)
 
@@ -251,7 +253,9 @@ def make_score_state_dict(seed=1, c_in=6, use_bn=True):
   sd = {}
   _trunk(rs, sd, 'encoderA', 'encoderAB', c_in, use_bn)
   _mha(rs, sd, 'att')
-  _mha(rs, sd, 'att_cross')
+  # with xavier-sized q/k the cross-hypothesis softmax is uniform and every hypothesis gets the same logit;
+  # a larger q/k gain makes the seeded scorer discriminate between hypotheses (hard parts)
+  _mha(rs, sd, 'att_cross', qk_gain=30.0)
   sd['pos_embed.pe'] = positional_embedding()
   _linear(rs, sd, 'linear', 1, 512)
   return sd

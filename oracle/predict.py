@@ -8,7 +8,7 @@ import torch
 from . import geometry as G
 from . import nets
 from .render import nvdiffrast_render
-from .warp import warp_perspective
+from .warp import warp_perspective, warp_perspective_nearest
 
 DEFAULT_REFINE_CFG = dict(input_resize=(160, 160), c_in=6, use_BN=True, normalize_xyz=True, use_normal=False,
                           crop_ratio=1.2, trans_rep='tracknet', rot_rep='axis_angle',
@@ -56,7 +56,7 @@ def make_crop_data_batch_refine(cfg, ob_in_cams, mesh_tensors, rgb, depth, K, xy
   tf_to_crops = G.compute_crop_window_tf_batch(poseA, K, cfg['crop_ratio'], (render_size[1], render_size[0]), mesh_diameter)
   rgb_rs, _, xyz_map_rs = _render_batch(cfg, K, H, W, poseA, mesh_tensors, tf_to_crops)
   rgbBs = warp_perspective(rgb.permute(2, 0, 1)[None].expand(B, -1, -1, -1), tf_to_crops, dsize=render_size, mode='bilinear', align_corners=False)
-  xyz_mapBs = warp_perspective(xyz_map.permute(2, 0, 1)[None].expand(B, -1, -1, -1), tf_to_crops, dsize=render_size, mode='nearest', align_corners=False)
+  xyz_mapBs = warp_perspective_nearest(xyz_map.permute(2, 0, 1)[None].expand(B, -1, -1, -1).contiguous(), tf_to_crops, render_size)
   mesh_diameters = torch.ones((B,), dtype=torch.float32) * mesh_diameter
   rgbAs = rgb_rs / 255.0
   rgbBs = rgbBs / 255.0
@@ -75,7 +75,7 @@ def make_crop_data_batch_score(cfg, ob_in_cams, mesh_tensors, rgb, depth, K, mes
   tf_to_crops = G.compute_crop_window_tf_batch(poseA, K, cfg['crop_ratio'], (render_size[1], render_size[0]), mesh_diameter)
   rgb_rs, depth_rs, xyz_map_rs = _render_batch(cfg, K, H, W, poseA, mesh_tensors, tf_to_crops)
   rgbBs = warp_perspective(rgb.permute(2, 0, 1)[None].expand(B, -1, -1, -1), tf_to_crops, dsize=render_size, mode='bilinear', align_corners=False)
-  depthBs = warp_perspective(depth[None, None].expand(B, -1, -1, -1), tf_to_crops, dsize=render_size, mode='nearest', align_corners=False)
+  depthBs = warp_perspective_nearest(depth[None, None].expand(B, -1, -1, -1).contiguous(), tf_to_crops, render_size)
   mesh_diameters = torch.ones((B,), dtype=torch.float32) * mesh_diameter
   Ks = torch.as_tensor(np.asarray(K), dtype=torch.float32).reshape(1, 3, 3).expand(B, 3, 3)
   rgbAs = rgb_rs / 255.0
@@ -84,9 +84,9 @@ def make_crop_data_batch_score(cfg, ob_in_cams, mesh_tensors, rgb, depth, K, mes
   crop_to_oris = torch.linalg.inv(tf_to_crops)
   chunks = []
   for s in range(0, B, 16):   # the reference materialises (B,H,W,3) at once; chunked here for memory
-    depthBs_ori = warp_perspective(depthBs[s:s + 16], crop_to_oris[s:s + 16], dsize=(H, W), mode='nearest', align_corners=False)
+    depthBs_ori = warp_perspective_nearest(depthBs[s:s + 16], crop_to_oris[s:s + 16], (H, W))
     xyz_full = G.depth2xyzmap_batch(depthBs_ori[:, 0], Ks[s:s + 16], zfar=np.inf).permute(0, 3, 1, 2)
-    chunks.append(warp_perspective(xyz_full, tf_to_crops[s:s + 16], dsize=render_size, mode='nearest', align_corners=False))
+    chunks.append(warp_perspective_nearest(xyz_full, tf_to_crops[s:s + 16], render_size))
   xyz_mapBs = torch.cat(chunks, 0)
   xyz_mapBs = _xyz_transform(xyz_mapBs, poseA, mesh_diameters, cfg['normalize_xyz'], 0.1, True)
   return dict(rgbAs=rgbAs, rgbBs=rgbBs, xyz_mapAs=xyz_mapAs, xyz_mapBs=xyz_mapBs, depthAs=depth_rs, depthBs=depthBs,

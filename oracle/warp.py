@@ -60,6 +60,40 @@ def warp_perspective(src, M, dsize, mode='bilinear', padding_mode='zeros', align
   return F.grid_sample(src, grid, align_corners=align_corners, mode=mode, padding_mode=padding_mode)
 
 
+TIE_EPS = 1e-4
+
+
+def round_half_even_snapped(x):
+  """nearbyint with coordinates closer than TIE_EPS px to a half-integer treated as EXACT ties.
+
+  Why: with the axis-aligned crop transforms of this path some nearest-neighbour lookups are exact
+  ties in real arithmetic - e.g. the scorer's crop->full-res warp (h5_dataset.py:158) maps the
+  full-res pixel on the window edge to crop coordinate (tf q)*160/159 - 0.5 = -0.5 exactly.
+  kornia's float32 normalise/invert chain carries ~1e-5 px of noise, so in the reference itself
+  such a lookup lands on either side of the tie at random per hypothesis (implementation noise, not
+  algorithm).  The oracle and the HIP kernel both resolve every coordinate within TIE_EPS of a tie
+  as exact arithmetic + round-half-to-even does, which makes the result deterministic."""
+  f = torch.floor(x)
+  t = x - f
+  tie = (t - 0.5).abs() < TIE_EPS
+  even = torch.where(torch.remainder(f, 2) == 0, f, f + 1)
+  return torch.where(tie, even, torch.floor(x + 0.5)).long()
+
+
+def warp_perspective_nearest(src, M, dsize):
+  """warp_perspective(mode='nearest', padding_mode='zeros', align_corners=False): the same kornia
+  chain evaluated in float64, ties resolved by round_half_even_snapped.  src (B,C,H,W) float32."""
+  B, C, H, W = src.shape
+  grid = warp_grid(M.double(), (H, W), dsize)
+  x = ((grid[..., 0] + 1) * W - 1) / 2
+  y = ((grid[..., 1] + 1) * H - 1) / 2
+  ix, iy = round_half_even_snapped(x), round_half_even_snapped(y)
+  inb = (ix >= 0) & (ix < W) & (iy >= 0) & (iy < H)
+  lin = (iy.clamp(0, H - 1) * W + ix.clamp(0, W - 1)).reshape(B, 1, -1).expand(B, C, -1)
+  out = torch.gather(src.reshape(B, C, H * W), 2, lin).reshape(B, C, dsize[0], dsize[1])
+  return out * inb[:, None].to(out.dtype)
+
+
 def source_affine_coeffs(M, src_hw, dsize):
   """Closed form of the map above for an axis-aligned M = [[sx,0,tx],[0,sy,ty],[0,0,1]]:
   output pixel (i,j) samples un-normalised source position

@@ -140,9 +140,11 @@ def test_fused_crop_tensors_match_oracle(sc, fp, which):
   # B, float32 output: rgb (bilinear) tight, xyz (nearest) with the boundary allowance
   f_rgb, m_rgb, _ = util.mismatch_report(B_ref[:, :3].numpy(), Bf32[:, :3].cpu().numpy(), 2e-5)
   assert f_rgb <= 1e-4, f'rgbB: {f_rgb:.2e} (max {m_rgb:.2e})'
-  f_xyz, m_xyz, _ = util.mismatch_report(B_ref[:, 3:].numpy(), Bf32[:, 3:].cpu().numpy(), 1e-5)
+  # nearest lookups: oracle and kernel share the tie rule of oracle/warp.py:round_half_even_snapped
+  lo = 0
+  f_xyz, m_xyz, _ = util.mismatch_report(B_ref[:, 3:, lo:, lo:].numpy(), Bf32[:, 3:, lo:, lo:].cpu().numpy(), 1e-5)
   assert f_xyz <= 5e-4, f'xyzB: {f_xyz:.2e} (max {m_xyz:.2e})'
-  fb, mb, _ = util.mismatch_report(B_ref.numpy(), B_g.numpy(), 1.5e-3)
+  fb, mb, _ = util.mismatch_report(B_ref[:, :, lo:, lo:].numpy(), B_g[:, :, lo:, lo:].numpy(), 1.5e-3)
   assert fb <= 5e-4
   assert float((B_ref[:, 3:] != 0).float().mean()) > 0.05     # the observed object is inside the crops
 
@@ -190,8 +192,8 @@ def test_pose_update(fp):
       ref, _, _ = OP.pose_update(cfg, torch.from_numpy(A), torch.from_numpy(trans), torch.from_numpy(rot), 0.191)
       out = torch.empty((n, 4, 4), device='cuda')
       tn = np.asarray(cfg['trans_normalizer'], dtype=np.float32)
-      check(lib().fp_pose_update(fp['ctx'].handle, ptr(torch.from_numpy(A).cuda()), ptr(torch.from_numpy(trans).cuda()),
-                                 ptr(torch.from_numpy(rot).cuda()), n, rot_dim, 0 if norm_xyz else 1, ptr(tn), cfg['rot_normalizer'],
+      A_d, t_d, r_d = torch.from_numpy(A).cuda(), torch.from_numpy(trans).cuda(), torch.from_numpy(rot).cuda()
+      check(lib().fp_pose_update(fp['ctx'].handle, ptr(A_d), ptr(t_d), ptr(r_d), n, rot_dim, 0 if norm_xyz else 1, ptr(tn), cfg['rot_normalizer'],
                                  np.float32(0.191 / 2) if norm_xyz else 1.0, ptr(out), stream_ptr()))
       np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-6)
 
@@ -240,10 +242,11 @@ def test_conv_igemm_vs_fp32_reference(fp, shape):
   if relu:
     ref = torch.relu(ref)
   wp = _pack_conv_weight(w.float(), cin_pad).cuda()
+  x_d, b_d = xin.cuda(), b.cuda()
   Ho, Wo = ref.shape[-2:]
   for out_f32 in (0, 1):
     out = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else torch.float16, device='cuda')
-    check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(xin.cuda()), N, H, W, cin_pad, ptr(wp), ptr(b.cuda()), Cout, k, k, stride, pad,
+    check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(x_d), N, H, W, cin_pad, ptr(wp), ptr(b_d), Cout, k, k, stride, pad,
                               ptr(res_d) if use_res else None, 1 if relu else 0, ptr(out), out_f32, stream_ptr()))
     got = out.float().permute(0, 3, 1, 2).cpu()
     scale = float(ref.abs().max())
@@ -272,7 +275,8 @@ def test_attention_vs_reference(fp):
   vt = torch.zeros((B, 4, 128, 416), dtype=torch.float16)
   vt[..., :T] = v.reshape(B, T, 4, 128).permute(0, 2, 3, 1)
   out = torch.empty((B * T, 512), dtype=torch.float16, device='cuda')
-  check(lib().fp_attention_f16(fp['ctx'].handle, ptr(qk.cuda()), ptr(vt.cuda()), B, T, ptr(out), stream_ptr()))
+  qk_d, vt_d = qk.cuda(), vt.cuda()
+  check(lib().fp_attention_f16(fp['ctx'].handle, ptr(qk_d), ptr(vt_d), B, T, ptr(out), stream_ptr()))
   q = qk[:, :512].float().reshape(B, T, 4, 128).transpose(1, 2)
   k = qk[:, 512:].float().reshape(B, T, 4, 128).transpose(1, 2)
   vv = v.float().reshape(B, T, 4, 128).transpose(1, 2)

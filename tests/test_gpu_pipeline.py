@@ -1,0 +1,193 @@
+"""GPU parity of the networks and of the whole register()/track_one() path against the CPU oracle
+and against the reference-generated golden vectors, through the Python mirror of the reference API
+(which calls the C-ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.test_oracle_golden import net_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def to_net_tensor(A, B):
+  """(n,6,160,160) fp32 A,B -> fp16 NHWC8 [2n][160][160][8] on the device (A first, then B)."""
+  x = torch.cat([A, B], 0).permute(0, 2, 3, 1)
+  out = torch.zeros((x.shape[0], 160, 160, 8), dtype=torch.float16)
+  out[..., :6] = x.half()
+  return out.cuda().contiguous()
+
+
+@pytest.fixture(scope='module')
+def nets_gpu():
+  from foundationpose_amd import _lib, synthetic as S
+  ctx = _lib.Context.get('cuda:0')
+  rsd, ssd = S.make_refine_state_dict(0), S.make_score_state_dict(1)
+  return dict(ctx=ctx, rsd=rsd, ssd=ssd, rnet=_lib.DeviceNet(ctx, _lib.FP_NET_REFINE, rsd, True),
+              snet=_lib.DeviceNet(ctx, _lib.FP_NET_SCORE, ssd, True), L=_lib)
+
+
+def _refine_gpu(ng, net, A, B):
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  n = len(A)
+  x = to_net_tensor(A, B)
+  trans = torch.empty((n, 3), device='cuda')
+  rot = torch.empty((n, net.rot_dim), device='cuda')
+  check(lib().fp_refine_forward(ng['ctx'].handle, net.handle, ptr(x), n, ptr(trans), ptr(rot), stream_ptr()))
+  return trans.cpu(), rot.cpu()
+
+
+def test_refine_net_vs_reference_golden(nets_gpu, golden):
+  """The HIP RefineNet against the outputs of the REFERENCE's own nn.Module (fp32, CPU) on the
+  golden inputs.  fp16 operands / fp32 accumulate through 17 GEMM layers: the outputs are O(0.1);
+  tolerance 2e-3 absolute (the reference itself runs this net under fp16 autocast)."""
+  A, B = net_inputs(11, 2)
+  trans, rot = _refine_gpu(nets_gpu, nets_gpu['rnet'], A, B)
+  np.testing.assert_allclose(trans.numpy(), golden['refine_trans'], atol=2e-3)
+  np.testing.assert_allclose(rot.numpy(), golden['refine_rot'], atol=2e-3)
+
+
+def test_refine_net_no_bn_6d_vs_golden(nets_gpu, golden):
+  from foundationpose_amd import _lib, synthetic as S
+  sd = S.make_refine_state_dict(seed=2, use_bn=False, rot_out_dim=6)
+  net = _lib.DeviceNet(nets_gpu['ctx'], _lib.FP_NET_REFINE, sd, use_bn=False)
+  assert net.rot_dim == 6
+  A, B = net_inputs(12, 1)
+  trans, rot = _refine_gpu(nets_gpu, net, A, B)
+  np.testing.assert_allclose(trans.numpy(), golden['refine_nobn_trans'], atol=2e-3)
+  np.testing.assert_allclose(rot.numpy(), golden['refine_nobn_rot'], atol=2e-3)
+
+
+def test_score_net_vs_reference_golden(nets_gpu, golden):
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  A, B = net_inputs(13, 4)
+  x = to_net_tensor(A, B)
+  feats = torch.empty((4, 512), device='cuda')
+  check(lib().fp_score_features(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(x), 4, ptr(feats), stream_ptr()))
+  scale = float(np.abs(golden['score_feats']).max())
+  np.testing.assert_allclose(feats.cpu().numpy(), golden['score_feats'], atol=3e-3 * scale)
+  for L, key in ((4, 'score_logit_L4'), (2, 'score_logit_L2')):
+    logits = torch.empty((4 // L, L), device='cuda')
+    am = torch.empty((4 // L,), dtype=torch.int32, device='cuda')
+    check(lib().fp_score_tail(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(feats), 4 // L, L, ptr(logits), ptr(am), stream_ptr()))
+    np.testing.assert_allclose(logits.cpu().numpy(), golden[key], atol=2e-3)
+    # the tail itself (fp32 SIMT) on the REFERENCE features must reproduce the reference logits tightly
+    fref = torch.from_numpy(golden['score_feats']).cuda()
+    check(lib().fp_score_tail(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(fref), 4 // L, L, ptr(logits), ptr(am), stream_ptr()))
+    np.testing.assert_allclose(logits.cpu().numpy(), golden[key], atol=2e-5)
+    np.testing.assert_array_equal(am.cpu().numpy(), golden[key].argmax(-1))
+
+
+def test_state_dict_errors(nets_gpu):
+  from foundationpose_amd import _lib
+  sd = dict(nets_gpu['rsd'])
+  sd.pop('encodeAB.2.net.0.weight')
+  with pytest.raises(_lib.FoundationPoseAmdError, match='encodeAB.2.net.0.weight'):
+    _lib.DeviceNet(nets_gpu['ctx'], _lib.FP_NET_REFINE, sd, True)
+  with pytest.raises(_lib.FoundationPoseAmdError):
+    _lib.DeviceNet(nets_gpu['ctx'], _lib.FP_NET_SCORE, nets_gpu['rsd'], True)   # wrong key family
+
+
+@pytest.fixture(scope='module')
+def estimators():
+  """FoundationPose (HIP) and the oracle on the same scene, rotation grid and weights."""
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.config import REFINE_DEFAULT, SCORE_DEFAULT
+  from foundationpose_amd.estimater import FoundationPose
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+  from foundationpose_amd.predict_score import ScorePredictor
+  from oracle.predict import OracleFoundationPose
+  sc = util.scene(0)
+  rsd, ssd = S.make_refine_state_dict(0), S.make_score_state_dict(1)
+  mesh = S.make_mustard_mesh(seed=0)
+  refiner = PoseRefinePredictor(state_dict=rsd, cfg=REFINE_DEFAULT)
+  scorer = ScorePredictor(state_dict=ssd, cfg=SCORE_DEFAULT)
+  np.random.seed(0)
+  est = FoundationPose(model_pts=mesh.vertices, model_normals=mesh.vertex_normals, mesh=mesh, refiner=refiner, scorer=scorer)
+  # the rotation grid is an input fixture shared by both sides (icosphere order is unpinned)
+  np.testing.assert_allclose(est.rot_grid.cpu().numpy(), sc['grid'], atol=1e-6)
+  assert est.rot_grid.shape == (252, 4, 4)
+  assert abs(est.diameter - sc['diameter']) < 2e-3
+  est.diameter = sc['diameter']
+  orc = OracleFoundationPose(sc['mt'], sc['diameter'], est.model_center, sc['grid'], rsd, ssd,
+                             refine_cfg=dict(REFINE_DEFAULT), score_cfg=dict(SCORE_DEFAULT))
+  return dict(sc=sc, est=est, orc=orc)
+
+
+def test_register_matches_oracle_config0(estimators):
+  """BASELINE config[0] (32 hypotheses, est_refine_iter=1) and a 2-iteration run.
+  Per hypothesis: refined 4x4 pose within 1e-3 of the oracle (north_star tolerance); score logits
+  within the fp16 noise floor (<5 % of the logit spread across hypotheses); identical argmax and
+  best pose whenever the oracle's top-1/top-2 margin exceeds 4x the measured logit noise."""
+  from oracle import geometry as G
+  from oracle import predict as OP
+  sc, est, orc = estimators['sc'], estimators['est'], estimators['orc']
+  full_g, full_o = est.rot_grid, orc.rot_grid
+  try:
+    est.rot_grid, orc.rot_grid = full_g[:32].contiguous(), full_o[:32]
+    depth = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+    xyz_map = G.depth2xyzmap(depth, sc['K'])
+    poses0 = util.hypotheses(sc, 32)
+    for iteration in (1, 2):
+      pg, _ = est.refiner.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=sc['rgb'], depth=depth, K=sc['K'], ob_in_cams=poses0,
+                                  xyz_map=xyz_map, mesh_diameter=est.diameter, iteration=iteration)
+      po = OP.refine_predict(orc.refine_cfg, orc.refine_sd, sc['rgb'], depth, sc['K'], poses0, xyz_map, sc['mt'], sc['diameter'],
+                             iteration=iteration, chunk=16)
+      perr = float((pg.cpu() - po).abs().max())
+      print(f'iteration={iteration}: max |pose_gpu - pose_oracle| over 32 hypotheses = {perr:.2e}')
+      assert perr < 1e-3
+      # scoring on the ORACLE's refined poses (isolates the scorer from refinement noise)
+      sg, _ = est.scorer.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=sc['rgb'], depth=depth, K=sc['K'],
+                                 ob_in_cams=po.numpy(), mesh_diameter=est.diameter)
+      so = OP.score_predict(orc.score_cfg, orc.score_sd, sc['rgb'], depth, sc['K'], po.numpy(), sc['mt'], sc['diameter'], chunk=16)
+      sg, so = sg.cpu().numpy(), so.numpy()
+      # a common shift of all logits cannot change the ranking: split the error into common + differential
+      common = float((sg - so).mean())
+      noise, spread = float(np.abs((sg - sg.mean()) - (so - so.mean())).max()), float(so.std())
+      top = np.sort(so)[::-1]
+      margin = float(top[0] - top[1])
+      print(f'iteration={iteration}: logit common shift {common:.2e}, differential noise {noise:.2e}, spread {spread:.2e}, '
+            f'top1-top2 margin {margin:.2e}, argmax gpu/oracle {int(sg.argmax())}/{int(so.argmax())}')
+      assert abs(common) < 5e-3 and noise < 0.25 * spread
+      if margin > 4 * noise:
+        assert int(sg.argmax()) == int(so.argmax())
+      # the integrated call
+      pose_g = est.register(K=sc['K'], rgb=sc['rgb'], depth=sc['depth'], ob_mask=sc['mask'], iteration=iteration)
+      pose_o = orc.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=iteration, chunk=16)
+      assert pose_g.dtype == np.float32 and pose_g.shape == (4, 4)
+      assert est.poses.shape == (32, 4, 4) and est.scores.shape == (32,)
+      assert bool((est.scores[:-1] >= est.scores[1:]).all())
+      if margin > 4 * noise and int(est.best_id) == int(orc.best_id):
+        np.testing.assert_allclose(pose_g, pose_o, atol=1e-3)
+  finally:
+    est.rot_grid, orc.rot_grid = full_g, full_o
+
+
+def test_register_degenerate_inputs(estimators):
+  """The reference's guards (src/estimater.py:139-147,185-189,251-253)."""
+  from foundationpose_amd.estimater import FoundationPose
+  sc, est = estimators['sc'], estimators['est']
+  empty = np.zeros_like(sc['mask'])
+  pose = est.register(K=sc['K'], rgb=sc['rgb'], depth=sc['depth'], ob_mask=empty, iteration=1)
+  assert pose.dtype == np.float64 and np.array_equal(pose, np.eye(4))
+  tiny = empty.copy(); tiny[240, 320] = True; tiny[240, 321] = True
+  pose = est.register(K=sc['K'], rgb=sc['rgb'], depth=sc['depth'], ob_mask=tiny, iteration=1)
+  assert np.array_equal(pose[:3, :3], np.eye(3)) and pose[2, 3] > 0
+  fresh = object.__new__(FoundationPose)
+  fresh.pose_last = None
+  with pytest.raises(RuntimeError):
+    fresh.track_one(sc['rgb'], sc['depth'], sc['K'], iteration=2)
+
+
+def test_track_one_matches_oracle(estimators):
+  sc, est, orc = estimators['sc'], estimators['est'], estimators['orc']
+  start = torch.as_tensor(util.hypotheses(sc, 1)[0])
+  start[:3, :3] = torch.as_tensor(sc['gt_pose'][:3, :3])
+  est.pose_last = start.cuda()
+  orc.pose_last = start.clone()
+  for _ in range(2):
+    pg = est.track_one(sc['rgb'], sc['depth'], sc['K'], iteration=2)
+    po = orc.track_one(sc['rgb'], sc['depth'], sc['K'], iteration=2)
+    assert pg.shape == (4, 4)
+    np.testing.assert_allclose(pg, po, atol=1e-3)
