@@ -1,0 +1,189 @@
+"""Benchmark: pose-hypotheses/sec of the render-and-compare hot path (render + refine x5 + score +
+argmax) on 252 hypotheses x 160x160 crops per object - BASELINE.json's metric on configs[1].
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one register-core pass: est_refine_iter=5 x (crop window, render,
+observed crop, RefineNet, pose update) + 1 x (crop window, render, observed crop, ScoreNet features)
++ cross-hypothesis tail + argmax, with the RGB-D frame, mesh, weights and hypotheses already resident
+in HBM.  With N GPUs the job is N objects x 252 hypotheses (weak scaling); every object's hypotheses
+are sharded over all ranks and one RCCL all-gather of [feature|pose] rows precedes the per-object
+tails (foundationpose_amd/dist.py).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+N_HYP = 252
+ITER = 5
+PEAK_F16_TFLOPS = 2500.0     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def build_job(device, n_objects, rank):
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.Utils import nvdiffrast_render
+  from foundationpose_amd.config import REFINE_DEFAULT, SCORE_DEFAULT
+  from foundationpose_amd.estimater import FoundationPose
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+  from foundationpose_amd.predict_score import ScorePredictor
+  from foundationpose_amd.Utils import bilateral_filter_depth, depth2xyzmap, erode_depth
+  mesh = S.make_mustard_mesh(seed=0)
+  refiner = PoseRefinePredictor(state_dict=S.make_refine_state_dict(0), cfg=REFINE_DEFAULT, device=device)
+  scorer = ScorePredictor(state_dict=S.make_score_state_dict(1), cfg=SCORE_DEFAULT, device=device)
+  np.random.seed(0)
+  est = FoundationPose(model_pts=mesh.vertices, model_normals=mesh.vertex_normals, mesh=mesh, refiner=refiner, scorer=scorer)
+  assert est.rot_grid.shape[0] == N_HYP
+  mt = est.mesh_tensors
+
+  def rf(K, H, W, pose):
+    c, d, _ = nvdiffrast_render(K=K, H=H, W=W, ob_in_cams=torch.as_tensor(pose, device=device), mesh_tensors=mt, use_light=True)
+    return c[0].cpu().numpy(), d[0].cpu().numpy()
+  objects = []
+  for o in range(n_objects):
+    sc = S.make_scene(rf, mt, seed=o)
+    depth = bilateral_filter_depth(erode_depth(sc['depth'], radius=2), radius=2)
+    center = est.guess_translation(depth=depth, mask=sc['mask'], K=sc['K'])
+    poses = est.rot_grid.clone()
+    poses[:, :3, 3] = torch.as_tensor(center, device=device, dtype=torch.float)
+    objects.append(dict(K=sc['K'], rgb=torch.as_tensor(sc['rgb'], device=device, dtype=torch.float).contiguous(),
+                        depth=torch.as_tensor(depth, device=device, dtype=torch.float).contiguous(),
+                        xyz=torch.as_tensor(depth2xyzmap(depth, sc['K']), device=device).contiguous(), poses=poses,
+                        rgb_np=sc['rgb'], depth_np=depth, mask=sc['mask']))
+  return est, objects
+
+
+def step(est, objects, world, rank):
+  """One register-core pass over all objects; returns per-object (best index, best pose) finalised on
+  the owning rank (object o is finalised by rank o % world)."""
+  from foundationpose_amd.dist import all_gather_rows, pack_rows, shard_ranges, unpack_rows
+  shard = math.ceil(N_HYP / world)
+  blocks = []
+  for ob in objects:
+    a, b = shard_ranges(N_HYP, world)[rank]
+    refined, _ = est.refiner.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=ob['rgb'], depth=ob['depth'], K=ob['K'],
+                                     ob_in_cams=ob['poses'][a:b], xyz_map=ob['xyz'], glctx=est.glctx, mesh_diameter=est.diameter,
+                                     iteration=ITER)
+    feats = est.scorer.extract_features(ob['rgb'], ob['depth'], ob['K'], refined, mesh=est.mesh, mesh_tensors=est.mesh_tensors,
+                                        glctx=est.glctx, mesh_diameter=est.diameter)
+    blocks.append((feats, refined))
+  results = {}
+  if world > 1:
+    rows = torch.cat([pack_rows(f, p, shard) for f, p in blocks], 0)          # (O*shard, 528)
+    gathered = all_gather_rows(rows).reshape(world, len(objects), shard, -1)     # ONE all-gather per step
+  for o, ob in enumerate(objects):
+    if o % world != rank:
+      continue
+    if world > 1:
+      feats_all, poses_all = unpack_rows(gathered[:, o].reshape(world * shard, -1), N_HYP, world)
+    else:
+      feats_all, poses_all = blocks[o]
+    logits, am = est.scorer.score_tail(feats_all, L=N_HYP)
+    results[o] = (am, poses_all)
+  return results
+
+
+def cpu_baseline():
+  """The CPU oracle timed on this host's cores on a bounded sample of the same workload."""
+  from tests import util
+  from oracle.predict import OracleFoundationPose
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.config import REFINE_DEFAULT, SCORE_DEFAULT
+  # the GPU box exposes 256 logical CPUs but one GPU's share is 16: more threads only oversubscribe
+  cores = min(os.cpu_count() or 1, 16)
+  os.environ['OMP_NUM_THREADS'] = str(cores)
+  torch.set_num_threads(cores)
+  sc = util.scene(0)
+  n_s = 16
+  orc = OracleFoundationPose(sc['mt'], sc['diameter'], sc['center'], sc['grid'][:n_s], S.make_refine_state_dict(0),
+                             S.make_score_state_dict(1), refine_cfg=dict(REFINE_DEFAULT), score_cfg=dict(SCORE_DEFAULT))
+  t0 = time.time()
+  orc.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=ITER, chunk=16)
+  dt = time.time() - t0
+  return dict(value=n_s / dt, unit='pose-hypotheses/sec', cores=cores, kind='port',
+              sample=f'{n_s} hypotheses of the same scene, est_refine_iter={ITER} + score, oracle/ (torch-CPU fp32 nets + C/OpenMP '
+                     f'rasteriser), {dt:.1f} s wall incl. depth filtering')
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=3)
+  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+  torch.cuda.set_device(local_rank)
+  device = torch.device('cuda', local_rank)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', device_id=device)
+
+  est, objects = build_job(device, n_objects=world, rank=rank)
+  ctx = est.refiner.ctx
+  ctx.reserve(N_HYP)
+
+  def barrier():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    step(est, objects, world, rank)
+  barrier()
+  ctx.prof_reset()
+  ctx.prof_enable(True)          # HIP events around every dominant-kernel launch, on the launch stream
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    res = step(est, objects, world, rank)
+  barrier()
+  dt = time.perf_counter() - t0
+  ctx.prof_enable(False)
+  conv = ctx.prof_read('conv3x3')
+  tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+  if world > 1:
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+  dt = float(tmax.item())
+
+  if rank == 0:
+    total_hyp = N_HYP * world * args.steps
+    achieved = conv['flops'] / (conv['total_ms'] * 1e-3) / 1e12 if conv['total_ms'] > 0 else 0.0
+    out = {
+      'metric': 'pose-hypotheses/sec (render+refine+score), 252 hyp x 160x160',
+      'value': total_hyp / dt, 'unit': 'pose-hypotheses/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+      'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'dtype': 'f16', 'data': 'synthetic',
+      'config': {'workload': 'configs[1]: single mesh (8066 v / 16128 f), 252 hypotheses, est_refine_iter=5, 160x160 crops, '
+                             '480x640 RGB-D frame; one such object per GPU, hypotheses sharded over all ranks',
+                 'hypotheses_per_object': N_HYP, 'objects': world, 'est_refine_iter': ITER, 'parallelism': f'hyp-shard x{world}',
+                 'weights': 'seeded random (reference state_dict layout)'},
+      'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (3x3 implicit-GEMM convolutions)', 'achieved': achieved,
+                   'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F16_TFLOPS,
+                   'avg_launch_ms': conv['total_ms'] / max(conv['launches'], 1), 'launches': conv['launches'], 'traffic': None},
+    }
+    if not args.no_cpu_baseline:
+      out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()
