@@ -191,6 +191,9 @@ static int launch_one(const ConvArgs &a, hipStream_t s) {
   return FP_OK;
 }
 
+bool conv_halo_supported(const ConvArgs &a);
+int launch_conv_halo(const ConvArgs &a, hipStream_t s);
+
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   FP_REQUIRE(a.Cin == 8 || a.Cin % 32 == 0, "conv: Cin=%d must be 8 or a multiple of 32", a.Cin);
   FP_REQUIRE(a.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", a.Cout);
@@ -202,6 +205,7 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const double flops = 2.0 * (double)a.M * a.Cout * a.KH * a.KW * (a.Cin == 8 ? 6 : a.Cin);
   const char *cls = (a.KW == 3) ? "conv3x3" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
+  if (conv_halo_supported(a)) return launch_conv_halo(a, s);
   const bool bm128 = (a.Cout % 128 == 0);
   if (a.Cin == 8) {
     FP_REQUIRE(a.KW == 7, "conv: Cin=8 path is the 7x7 stem");
