@@ -64,6 +64,11 @@ extern "C" int fp_ctx_create(int device, fp_ctx **out) {
   fp_ctx *c = new fp_ctx;
   c->device = device;
   c->num_cu = prop.multiProcessorCount;
+  if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+    delete c;
+    fp_set_error("fp_ctx_create: zero page allocation failed");
+    return FP_ENOMEM;
+  }
   *out = c;
   return FP_OK;
 }
@@ -77,6 +82,7 @@ extern "C" int fp_ctx_destroy(fp_ctx *ctx) {
     (void)hipEventDestroy(e.b);
   }
   if (ctx->arena.base) (void)hipFree(ctx->arena.base);
+  if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   delete ctx;
   return FP_OK;
 }

@@ -83,6 +83,7 @@ struct fp_ctx {
   std::map<std::string, ProfEntry> prof_tab;
   std::vector<PendingEvent> pending;
   int num_cu = 256;
+  void *zero_page = nullptr;   // 4 KB of zeros: DMA source for out-of-image taps
 };
 
 int fp_arena_ensure(fp_ctx *ctx, size_t bytes);

@@ -183,6 +183,191 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: 256 pixels x BM couts per workgroup, both operands staged by LDS-DMA (global_load_lds_dwordx4,
+// per-lane gather address, out-of-image taps read a zero page), XOR-swizzled 64-byte rows
+// (conflict-free ds_read_b128), 2 stages: the next K-step's DMA is in flight under the current
+// step's 16 MFMAs per wave.  Used for the 1x1 (Linear) layers, the stride-2 3x3 and the 7x7 stem.
+// ------------------------------------------------------------------------------------------------
+#define C2_BN 256
+#define C2_BK 32
+
+__device__ __forceinline__ void glds16c(const f16 *g, f16 *l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+template <int BM, int KW, bool CIN8>
+__global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f16 *__restrict__ zero_page) {
+  constexpr int XH = C2_BN * C2_BK, WH = BM * C2_BK;      // halfs per stage
+  __shared__ __attribute__((aligned(16))) f16 smem[2 * (XH + WH)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int WM = BM / 2, MT = WM / 32, NT = 4;
+  constexpr int WQ = BM / 64;                              // weight DMA instructions per wave per stage
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * C2_BN, c0 = blockIdx.y * BM;
+  const int HoWo = p.Ho * p.Wo;
+  const int ntaps = p.KH * p.KW;
+
+  // ---- DMA source bookkeeping: this lane feeds LDS chunk (px = (q*4+wave)*16 + lane/4, chp = lane&3) ----
+  const int chp = lane & 3;
+  long long xbase[4];
+  int iy0[4], ix0[4], xch[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int px = (q * 4 + wave) * 16 + (lane >> 2);
+    const int m = m0 + px;
+    const bool mv = m < p.M;
+    const int mm = mv ? m : 0;
+    const int n = mm / HoWo, rem = mm - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    iy0[q] = mv ? oy * p.stride - p.pad : -100000;          // invalid pixel -> every tap out of range
+    ix0[q] = ox * p.stride - p.pad;
+    xbase[q] = (long long)n * p.H * p.W * p.Cin;
+    xch[q] = chp ^ ((px >> 2) & 3);                          // source chunk (swizzle on the SOURCE side)
+  }
+  const f16 *wsrc[WQ];
+#pragma unroll
+  for (int q = 0; q < WQ; ++q) {
+    const int co = (q * 4 + wave) * 16 + (lane >> 2);
+    wsrc[q] = p.w + (size_t)(c0 + co) * p.Kpad + ((chp ^ ((co >> 2) & 3)) * 8);
+  }
+  auto stage = [&](int kt, int buf) {
+    f16 *xs = smem + buf * (XH + WH), *ws = xs + XH;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = kt * C2_BK + xch[q] * 8;
+      int tap, ci;
+      if (CIN8) {
+        tap = k >> 3;
+        ci = 0;
+      } else {
+        tap = (kt * C2_BK) / p.Cin;
+        ci = k - tap * p.Cin;
+      }
+      const int ky = tap / KW, kx = tap - ky * KW;
+      const int iy = iy0[q] + ky, ix = ix0[q] + kx;
+      const bool ok = tap < ntaps && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const f16 *src = ok ? p.in + xbase[q] + ((long long)iy * p.W + ix) * p.Cin + ci : zero_page;
+      glds16c(src, xs + (q * 4 + wave) * 512);
+    }
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) glds16c(wsrc[q] + (size_t)kt * C2_BK, ws + (q * 4 + wave) * 512);
+  };
+
+  // ---- fragment bases (swizzled rows: chunk ^ ((row>>2)&3); rows +32 keep the same swizzle) ----
+  int wa[2], xa[NT][2];
+  {
+    const int co = wm * WM + lr;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) wa[ks] = co * 32 + (((ks * 2 + lh) ^ ((co >> 2) & 3)) * 8);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int px = wn * 128 + j * 32 + lr;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) xa[j][ks] = px * 32 + (((ks * 2 + lh) ^ ((px >> 2) & 3)) * 8);
+    }
+  }
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.Kpad / C2_BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    __syncthreads();                       // stage kt landed (vmcnt drained before the barrier); buffer cur^1 is free
+    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const f16 *xs = smem + cur * (XH + WH), *ws = xs + XH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const half8 *>(&ws[wa[ks] + i * 32 * 32]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const half8 *>(&xs[xa[j][ks]]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue (same lane ownership as v1) ----
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int m = m0 + wn * 128 + j * 32 + lr;
+    if (m >= p.M) continue;
+    const bool hi = m >= p.split_m;
+    const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+    const int coff = hi ? p.coff_hi : 0;
+    int prow = 0;
+    if (p.post_add) prow = m % p.post_period;
+    int tb = 0, tt = 0;
+    if (p.out_mode == 2) {
+      tb = m / p.tokens;
+      tt = m - tb * p.tokens;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int co = c0 + wm * WM + i * 32 + rg * 8 + lh * 4;
+        float v[4];
+        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co);
+        v[0] = acc[i][j][rg * 4 + 0] + bv.x;
+        v[1] = acc[i][j][rg * 4 + 1] + bv.y;
+        v[2] = acc[i][j][rg * 4 + 2] + bv.z;
+        v[3] = acc[i][j][rg * 4 + 3] + bv.w;
+        if (p.res) {
+          half4 rv = *reinterpret_cast<const half4 *>(p.res + (size_t)m * p.Cout + co);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (p.post_add) {
+          const float4 pv = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + co);
+          v[0] += pv.x;
+          v[1] += pv.y;
+          v[2] += pv.z;
+          v[3] += pv.w;
+        }
+        if (p.out_mode == 0) {
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
+          *reinterpret_cast<half4 *>((f16 *)p.out + orow * p.out_ld + coff + co) = hv;
+        } else if (p.out_mode == 1) {
+          *reinterpret_cast<float4 *>((float *)p.out + orow * p.out_ld + coff + co) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = co + e, h = c >> 7, d = c & 127;
+            ((f16 *)p.out)[(((size_t)tb * 4 + h) * 128 + d) * 416 + tt] = (f16)v[e];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int KW, bool CIN8>
+static int launch_two(const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
+  dim3 grid((a.M + C2_BN - 1) / C2_BN, a.Cout / BM);
+  hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8>), grid, dim3(256), 0, s, a, zero_page);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
 template <int BM, int KW, bool CIN8>
 static int launch_one(const ConvArgs &a, hipStream_t s) {
   dim3 grid((a.M + CV_BN - 1) / CV_BN, a.Cout / BM);
@@ -207,11 +392,12 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   ProfScope ps(ctx, s, cls, flops);
   if (conv_halo_supported(a)) return launch_conv_halo(a, s);
   const bool bm128 = (a.Cout % 128 == 0);
+  const f16 *zp = (const f16 *)ctx->zero_page;
   if (a.Cin == 8) {
     FP_REQUIRE(a.KW == 7, "conv: Cin=8 path is the 7x7 stem");
-    return bm128 ? launch_one<128, 7, true>(a, s) : launch_one<64, 7, true>(a, s);
+    return bm128 ? launch_two<128, 7, true>(a, zp, s) : launch_two<64, 7, true>(a, zp, s);
   }
-  if (a.KW == 3) return bm128 ? launch_one<128, 3, false>(a, s) : launch_one<64, 3, false>(a, s);
-  if (a.KW == 1) return bm128 ? launch_one<128, 1, false>(a, s) : launch_one<64, 1, false>(a, s);
+  if (a.KW == 3) return bm128 ? launch_two<128, 3, false>(a, zp, s) : launch_two<64, 3, false>(a, zp, s);
+  if (a.KW == 1) return bm128 ? launch_two<128, 1, false>(a, zp, s) : launch_two<64, 1, false>(a, zp, s);
   FP_REQUIRE(false, "conv: unsupported configuration KW=%d Cin=%d", a.KW, a.Cin);
 }
