@@ -1,0 +1,89 @@
+"""CPU, world_size 2 over gloo: the hypothesis-sharding + single all-gather exchange of
+foundationpose_amd/dist.py (the N>1 path of bench.py / FoundationPose(dist_group=...))."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+
+
+def test_shard_ranges_cover_exactly():
+  from foundationpose_amd.dist import shard_ranges
+  for n in (0, 1, 7, 32, 64, 252, 1008):
+    for world in (1, 2, 3, 4, 8):
+      r = shard_ranges(n, world)
+      assert len(r) == world
+      assert r[0][0] == 0 and r[-1][1] == n
+      assert all(a <= b for a, b in r) and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+      sizes = [b - a for a, b in r]
+      assert max(sizes) == (-(-n // world) if n else 0)     # 252/8 -> 32 x7 + 28
+
+
+def test_pack_unpack_roundtrip_single_process():
+  """Emulates the all-gather for 8 ranks in one process: concatenating every rank's padded block and
+  unpacking must give back the rows in hypothesis order (252 is not divisible by 8)."""
+  from foundationpose_amd.dist import pack_rows, shard_ranges, unpack_rows
+  n, world = 252, 8
+  g = torch.Generator().manual_seed(0)
+  feats, poses = torch.randn((n, 512), generator=g), torch.randn((n, 4, 4), generator=g)
+  shard = -(-n // world)
+  blocks = [pack_rows(feats[a:b], poses[a:b], shard) for a, b in shard_ranges(n, world)]
+  f2, p2 = unpack_rows(torch.cat(blocks, 0), n, world)
+  assert torch.equal(f2, feats) and torch.equal(p2, poses)
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _worker(rank, world, port, cases, out_q):
+  sys.path.insert(0, REPO)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  from foundationpose_amd.dist import all_gather_rows, pack_rows, shard_ranges, unpack_rows
+  for n, n_obj in cases:
+    shard = -(-n // world)
+    g = torch.Generator().manual_seed(123)            # every rank can regenerate the full truth
+    feats = torch.randn((n_obj, n, 512), generator=g)
+    poses = torch.randn((n_obj, n, 4, 4), generator=g)
+    a, b = shard_ranges(n, world)[rank]
+    # bench.py layout: every object's shard of this rank, stacked, ONE all-gather
+    rows = torch.cat([pack_rows(feats[o, a:b], poses[o, a:b], shard) for o in range(n_obj)], 0)
+    gathered = all_gather_rows(rows).reshape(world, n_obj, shard, -1)
+    ok = True
+    for o in range(n_obj):
+      f2, p2 = unpack_rows(gathered[:, o].reshape(world * shard, -1), n, world)
+      ok = ok and torch.equal(f2, feats[o]) and torch.equal(p2, poses[o])
+    # the cross-hypothesis tail sees identical inputs on every rank -> identical argmax
+    am = int((gathered[..., :512].sum(-1)).reshape(-1).argmax())
+    out_q.put((rank, n, ok, am))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_all_gather_exchange_world2():
+  world = 2
+  cases = [(252, 2), (7, 1), (1, 1)]     # 252 hypotheses x 2 objects; ragged; fewer hypotheses than ranks
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, cases, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = [q.get(timeout=180) for _ in range(world * len(cases))]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  assert all(ok for _, _, ok, _ in res)
+  for n, _ in cases:
+    assert len({am for _, nn, _, am in res if nn == n}) == 1

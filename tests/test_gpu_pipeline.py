@@ -191,3 +191,28 @@ def test_track_one_matches_oracle(estimators):
     po = orc.track_one(sc['rgb'], sc['depth'], sc['K'], iteration=2)
     assert pg.shape == (4, 4)
     np.testing.assert_allclose(pg, po, atol=1e-3)
+
+
+def test_register_through_dist_group_world1(estimators):
+  """The sharded path (foundationpose_amd/dist.py) over RCCL with a single rank must reproduce the
+  plain path bit for bit (same kernels, same order; the all-gather is the identity)."""
+  import os
+  import torch.distributed as dist
+  sc, est = estimators['sc'], estimators['est']
+  full = est.rot_grid
+  os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+  os.environ.setdefault('MASTER_PORT', '29617')
+  dist.init_process_group('nccl', rank=0, world_size=1)
+  try:
+    est.rot_grid = full[:16].contiguous()
+    p0 = est.register(K=sc['K'], rgb=sc['rgb'], depth=sc['depth'], ob_mask=sc['mask'], iteration=2)
+    s0, id0 = est.scores.clone(), int(est.best_id)
+    est.dist_group = dist.group.WORLD
+    p1 = est.register(K=sc['K'], rgb=sc['rgb'], depth=sc['depth'], ob_mask=sc['mask'], iteration=2)
+    assert int(est.best_id) == id0
+    np.testing.assert_array_equal(p1, p0)
+    assert torch.equal(est.scores, s0)
+  finally:
+    est.dist_group = None
+    est.rot_grid = full
+    dist.destroy_process_group()
