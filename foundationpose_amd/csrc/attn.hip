@@ -7,7 +7,7 @@
 // src/Utils.py:848-855.
 #include "common.h"
 
-#define AT_WAVES 5
+#define AT_WAVES 10
 #define AT_THREADS (AT_WAVES * 64)
 #define AT_DH 128
 #define AT_KLD 136   // halfs per K row in LDS (128 + 8 pad)  -> 272 B
@@ -32,13 +32,23 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__rest
   const int ntile = (T + 15) / 16;  // key tiles (25)
   const size_t rowbase = (size_t)b * T;
 
-  // ---- stage K (T x 128) into LDS, zero-fill the tail rows of the last tile ----
+  // ---- stage K (T x 128) into LDS, zero-fill the tail rows of the last tile.  Loads are issued in batches
+  //      of 5 before the first ds_write so that their latencies overlap (a load->store loop serialises them) ----
   const int kchunks = ntile * 16 * (AT_DH / 8);
-  for (int c = tid; c < kchunks; c += AT_THREADS) {
-    int key = c >> 4, ch = c & 15;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (key < T) v = *reinterpret_cast<const uint4 *>(qk + (rowbase + key) * 1024 + 512 + h * AT_DH + ch * 8);
-    *reinterpret_cast<uint4 *>(&smem[key * AT_KLD + ch * 8]) = v;
+#pragma unroll 1
+  for (int c0 = tid; c0 < kchunks; c0 += AT_THREADS * 5) {
+    uint4 v[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int c = c0 + u * AT_THREADS, key = c >> 4, ch = c & 15;
+      v[u] = make_uint4(0, 0, 0, 0);
+      if (c < kchunks && key < T) v[u] = *reinterpret_cast<const uint4 *>(qk + (rowbase + key) * 1024 + 512 + h * AT_DH + ch * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int c = c0 + u * AT_THREADS, key = c >> 4, ch = c & 15;
+      if (c < kchunks) *reinterpret_cast<uint4 *>(&smem[key * AT_KLD + ch * 8]) = v[u];
+    }
   }
   // ---- Q fragments: B operand, lane (q = lq, g) holds Q[q][32s + 8g .. +7] ----
   const int q = qb * (AT_WAVES * 16) + wave * 16 + lq;
@@ -93,11 +103,23 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__rest
   const float inv = 1.f / sum;
   __syncthreads();  // everyone is done reading K from LDS
 
-  // ---- stage V^T (128 x 416) into LDS ----
+  // ---- stage V^T (128 x 416) into LDS (batched loads, as for K) ----
   const f16 *vsrc = vt + ((size_t)b * 4 + h) * AT_DH * AT_TP;
-  for (int c = tid; c < AT_DH * (AT_TP / 8); c += AT_THREADS) {
-    int d = c / (AT_TP / 8), ch = c - d * (AT_TP / 8);
-    *reinterpret_cast<uint4 *>(&smem[d * AT_VLD + ch * 8]) = *reinterpret_cast<const uint4 *>(vsrc + (size_t)d * AT_TP + ch * 8);
+  constexpr int VCH = AT_DH * (AT_TP / 8);
+#pragma unroll 1
+  for (int c0 = tid; c0 < VCH; c0 += AT_THREADS * 7) {
+    uint4 v[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int c = c0 + u * AT_THREADS;
+      v[u] = make_uint4(0, 0, 0, 0);
+      if (c < VCH) v[u] = *reinterpret_cast<const uint4 *>(vsrc + (size_t)c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int c = c0 + u * AT_THREADS, d = c / (AT_TP / 8), ch = c - d * (AT_TP / 8);
+      if (c < VCH) *reinterpret_cast<uint4 *>(&smem[d * AT_VLD + ch * 8]) = v[u];
+    }
   }
   __syncthreads();
 

@@ -16,6 +16,7 @@
 // step's loads issued before the current step's MFMAs, LDS rows padded to 80 B (conflict-free
 // ds_read_b128 fragment reads), double-buffered, one barrier per K-step.
 #include "common.h"
+#include <cstdlib>
 
 #define CV_BN 128
 #define CV_BK 32

@@ -32,7 +32,7 @@ struct HaloCfg {
   static constexpr int HALO_CHUNKS = MAXSLOT * W * 4;              // 16-byte chunks (4 per pixel at 32 channels)
   static constexpr int HALO_HALFS = (MAXSLOT * W + 2) * HL_PS + 8; // pixel p lives at index p+1; + one zero chunk
   static constexpr int ZERO_OFF = (MAXSLOT * W + 2) * HL_PS;       // half offset of the zero chunk
-  static constexpr int HALO_LOADS = (HALO_CHUNKS + 255) / 256;
+  static constexpr int halo_loads(int nth) { return (HALO_CHUNKS + nth - 1) / nth; }
   static constexpr int WBUF_HALFS = 3 * HL_BM * HL_CK;             // one kernel row of taps
   static constexpr int LDS_HALFS_MAIN = HALO_HALFS + 2 * WBUF_HALFS;
   static constexpr int LDS_HALFS_EPI = HL_TM * HL_SLD;
@@ -43,15 +43,22 @@ __device__ __forceinline__ void glds16(const f16 *g, f16 *l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-template <int W>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
+// NWN = wave columns: 2 -> 4 waves, each 64 co x 128 px (2x4 tiles, <=256 VGPRs, 2 waves/SIMD at 2 WG/CU);
+//                     4 -> 8 waves, each 64 co x 64 px (2x2 tiles, <=128 VGPRs, 4 waves/SIMD at 2 WG/CU)
+template <int W, int NWN>
+__global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p) {
   using C = HaloCfg<W>;
   constexpr int H = W;
+  constexpr int NTH = 128 * NWN;        // threads
+  constexpr int NT = 8 / NWN;           // 32-pixel tiles per wave
+  constexpr int PXW = 32 * NT;          // pixels per wave
+  constexpr int HLOADS = C::halo_loads(NTH);
+  constexpr int WQ = 24 / (2 * NWN);    // weight DMA instructions per wave per group
   extern __shared__ __attribute__((aligned(16))) f16 lds[];
   f16 *halo = lds;
   f16 *wbuf = lds + C::HALO_HALFS;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.x * HL_TM, c0 = blockIdx.y * HL_BM;
   const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by slot 0
@@ -61,11 +68,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   const int nchunk = p.Cin / HL_CK;
 
   // ---- per-lane B-fragment bases: pixel (slot(ky), ox) for the 4 pixel tiles of this wave ----
-  int pb[4];         // LDS half-offset of the top-left tap; tap (ky,kx), k-step ks add the immediate ((ky*W+kx)*40 + ks*16)
-  unsigned vmask[4]; // bit (ky*3+kx): tap inside the image
+  int pb[NT];         // LDS half-offset of the top-left tap; tap (ky,kx), k-step ks add the immediate ((ky*W+kx)*40 + ks*16)
+  unsigned vmask[NT]; // bit (ky*3+kx): tap inside the image
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + wn * 128 + j * 32 + lr;
+  for (int j = 0; j < NT; ++j) {
+    int m = m0 + wn * PXW + j * 32 + lr;
     m = min(m, p.M - 1);
     const int gr = m / W, ox = m - gr * W, oy = gr % H;
     pb[j] = ((gr - GR0) * W + ox - W) * HL_PS + lh * 8;   // top-left tap (ky=0,kx=0) of this pixel, k-half lh
@@ -89,11 +96,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   }
 
   // ---- halo staging: global -> registers (prefetch) -> LDS ----
-  uint4 hreg[C::HALO_LOADS];
+  uint4 hreg[HLOADS];
   auto halo_load = [&](int cc) {
 #pragma unroll
-    for (int i = 0; i < C::HALO_LOADS; ++i) {
-      const int idx = tid + 256 * i;
+    for (int i = 0; i < HLOADS; ++i) {
+      const int idx = tid + NTH * i;
       const int pix = idx >> 2, ch = idx & 3;        // pix = slot*W + px
       const int slot = pix / W;
       const int gr = GR0 + slot;
@@ -105,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   };
   auto halo_store = [&]() {
 #pragma unroll
-    for (int i = 0; i < C::HALO_LOADS; ++i) {
-      const int idx = tid + 256 * i;
+    for (int i = 0; i < HLOADS; ++i) {
+      const int idx = tid + NTH * i;
       const int pix = idx >> 2, ch = idx & 3;
       if (idx < C::HALO_CHUNKS) *reinterpret_cast<uint4 *>(&halo[(pix + 1) * HL_PS + ch * 8]) = hreg[i];
     }
@@ -114,20 +121,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   // ---- weights: one kernel row (3 taps) per group, LDS-DMA, lane-linear image with the swizzle on the SOURCE ----
   auto wstage = [&](int cc, int ky, int buf) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const int L = (q * 4 + wave) * 64 + lane;      // linear 16-byte position in the 3x128x4 image
+    for (int q = 0; q < WQ; ++q) {
+      const int L = (q * 2 * NWN + wave) * 64 + lane;  // linear 16-byte position in the 3x128x4 image
       const int kx = L >> 9, rem = L & 511, co = rem >> 2, chp = rem & 3;
       const int ch = chp ^ ((co >> 2) & 3);
       const f16 *src = p.w + (size_t)(c0 + co) * p.Kpad + (ky * 3 + kx) * p.Cin + cc * HL_CK + ch * 8;
-      glds16(src, wbuf + buf * C::WBUF_HALFS + (q * 4 + wave) * 512);
+      glds16(src, wbuf + buf * C::WBUF_HALFS + (q * 2 * NWN + wave) * 512);
     }
   };
 
-  floatx16 acc[2][4];
+  floatx16 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -155,9 +162,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
       if (ky == 0 && cc + 1 < nchunk) halo_load(cc + 1);
       const f16 *wb = wbuf + buf * C::WBUF_HALFS;
       // keep the per-tap border selects INSIDE the loop: hoisted, their 72 results would not fit the register file
-      unsigned vm[4];
+      unsigned vm[NT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NT; ++j) {
         vm[j] = vmask[j];
         asm volatile("" : "+v"(vm[j]));
       }
@@ -165,11 +172,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
       for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          half8 af[2], bf[4];
+          half8 af[2], bf[NT];
 #pragma unroll
           for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8 *>(&wb[wa[ks] + i * (32 * 32) + kx * (HL_BM * HL_CK)]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < NT; ++j) {
             constexpr int dummy = 0;
             const int imm = (ky * W + kx) * HL_PS + ks * 16;
             const bool ok = (vm[j] >> (ky * 3 + kx)) & 1u;
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
       }
     }
@@ -190,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   f16 *stage = lds;   // [256 px][HL_SLD]
   if (p.res) {
 #pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const int idx = tid + 256 * i, px = idx >> 4, c16 = idx & 15;
+    for (int i = 0; i < 4096 / NTH; ++i) {
+      const int idx = tid + NTH * i, px = idx >> 4, c16 = idx & 15;
       const int m = m0 + px;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (m < p.M) v = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
@@ -200,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
     __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int pxl = wn * 128 + j * 32 + lr;
+  for (int j = 0; j < NT; ++j) {
+    const int pxl = wn * PXW + j * 32 + lr;
     const int m = m0 + pxl;
     int prow = 0;
     if (p.post_add) prow = min(m, p.M - 1) % p.post_period;
@@ -239,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p) {
   }
   __syncthreads();
 #pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int idx = tid + 256 * i, px = idx >> 4, c16 = idx & 15;
+  for (int i = 0; i < 4096 / NTH; ++i) {
+    const int idx = tid + NTH * i, px = idx >> 4, c16 = idx & 15;
     const int m = m0 + px;
     if (m < p.M) {
       const bool hi = m >= p.split_m;
@@ -257,21 +264,27 @@ bool conv_halo_supported(const ConvArgs &a) {
          a.Cout % HL_BM == 0 && a.out_mode == 0 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0;
 }
 
-template <int W>
+template <int W, int NWN>
 static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
   using C = HaloCfg<W>;
   static bool attr_set = false;
   if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
   dim3 grid((a.M + HL_TM - 1) / HL_TM, a.Cout / HL_BM);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<W>), grid, dim3(256), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<W, NWN>), grid, dim3(128 * NWN), C::LDS_BYTES, s, a);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
 
+int g_halo_nwn = 2;   // tuning knob (FP_HALO_NWN env, read once in api.hip)
+
 int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
-  if (a.W == 40) return launch_halo_w<40>(a, s);
-  return launch_halo_w<20>(a, s);
+  if (g_halo_nwn == 2) {
+    if (a.W == 40) return launch_halo_w<40, 2>(a, s);
+    return launch_halo_w<20, 2>(a, s);
+  }
+  if (a.W == 40) return launch_halo_w<40, 4>(a, s);
+  return launch_halo_w<20, 4>(a, s);
 }

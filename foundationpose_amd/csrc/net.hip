@@ -3,7 +3,9 @@
 // (learning/models/score_network.py:60-90) as sequences of the gfx950 kernels in conv.hip / attn.hip.
 #include "common.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 
 struct ConvW {
@@ -32,6 +34,14 @@ struct fp_net {
   LinF32 att_out, cross_in, cross_out, lin;
   std::vector<void *> allocs;
 };
+
+// Hypotheses per network pass.  FP_CHUNK=n overrides; 0 = whole batch.
+static int fp_hyp_chunk(int n_total) {
+  static int env = getenv("FP_CHUNK") ? atoi(getenv("FP_CHUNK")) : -1;
+  int ch = env >= 0 ? env : 0;
+  if (ch <= 0 || ch > n_total) ch = n_total;
+  return ch;
+}
 
 namespace {
 
@@ -304,7 +314,7 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s) {
   }
 
 // shared trunk -> tokens (N*400, 512) fp16, positional embedding added
-int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *x, int N, f16 **tokens_out, hipStream_t s) {
+int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int N, f16 **tokens_out, hipStream_t s) {
   const ConvW *t = net->trunk;
   const size_t n2 = (size_t)2 * N;
   TAKE(a0, f16, n2 * 80 * 80 * 64);
@@ -320,7 +330,9 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *x, int N, f16 **tokens_
   TAKE(tok, f16, (size_t)N * 400 * 512);
   Conv2dCall c;
   // encodeA / encoderA on cat([A,B],0)
-  c = Conv2dCall{x, (int)n2, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s));
+  // (A and B halves of the net tensor may come from different places when the batch is processed in chunks)
+  c = Conv2dCall{xA, N, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{xB, N, 160, 160, &t[0]}; c.out = a0 + (size_t)N * 80 * 80 * 64; FP_TRY(run_conv(ctx, c, s));
   c = Conv2dCall{a0, (int)n2, 80, 80, &t[1]}; c.out = a1; FP_TRY(run_conv(ctx, c, s));
   c = Conv2dCall{a1, (int)n2, 40, 40, &t[2]}; c.out = tA; FP_TRY(run_conv(ctx, c, s));
   c = Conv2dCall{tA, (int)n2, 40, 40, &t[3]}; c.res = a1; c.out = a2; FP_TRY(run_conv(ctx, c, s));
@@ -363,11 +375,15 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
   FP_REQUIRE(N >= 0, "fp_refine_forward: N<0");
   if (N == 0) return FP_OK;
   hipStream_t s = (hipStream_t)stream;
-  FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(N)));
+  const int NT = N;                                   // whole batch
+  const int CH = fp_hyp_chunk(NT);
+  FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(CH)));
   const size_t mark = ctx->arena.off;
-  auto body = [&]() -> int {
+  const size_t img = (size_t)160 * 160 * 8;
+  auto body = [&](int s0, int N) -> int {
     f16 *tok = nullptr;
-    FP_TRY(run_trunk(ctx, net, (const f16 *)d_net_in, N, &tok, s));
+    const f16 *in = (const f16 *)d_net_in;
+    FP_TRY(run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, &tok, s));
     const int M = N * 400;
     TAKE(qk, f16, (size_t)M * 1024);
     TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
@@ -375,7 +391,7 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     TAKE(y32, float, (size_t)M * 512);
     TAKE(x1, f16, (size_t)M * 512);
     TAKE(ff, f16, (size_t)M * 512);
-    float *outs[2] = {d_trans, d_rot};
+    float *outs[2] = {d_trans + (size_t)s0 * 3, d_rot + (size_t)s0 * net->heads[1].out_dim};
     for (int h = 0; h < 2; ++h) {
       const HeadW &H = net->heads[h];
       FP_TRY(run_mha_core(ctx, H.qk, H.v, tok, N, qk, vt, att, s));
@@ -388,8 +404,13 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     }
     return FP_OK;
   };
-  int rc = body();
-  ctx->arena.off = mark;
+  // hypothesis chunks reuse the SAME arena addresses: a chunk's activations (<= ~0.9 GB at 72 hypotheses... sized by
+  // fp_hyp_chunk so that producer->consumer tensors stay resident in the 256 MiB Infinity Cache
+  int rc = FP_OK;
+  for (int s0 = 0; s0 < NT && rc == FP_OK; s0 += CH) {
+    rc = body(s0, std::min(CH, NT - s0));
+    ctx->arena.off = mark;
+  }
   return rc;
 }
 
@@ -399,11 +420,15 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
   FP_REQUIRE(N >= 0, "fp_score_features: N<0");
   if (N == 0) return FP_OK;
   hipStream_t s = (hipStream_t)stream;
-  FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(N)));
+  const int NT = N;
+  const int CH = fp_hyp_chunk(NT);
+  FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(CH)));
   const size_t mark = ctx->arena.off;
-  auto body = [&]() -> int {
+  const size_t img = (size_t)160 * 160 * 8;
+  auto body = [&](int s0, int N) -> int {
     f16 *tok = nullptr;
-    FP_TRY(run_trunk(ctx, net, (const f16 *)d_net_in, N, &tok, s));
+    const f16 *in = (const f16 *)d_net_in;
+    FP_TRY(run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, &tok, s));
     const int M = N * 400;
     TAKE(qk, f16, (size_t)M * 1024);
     TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
@@ -412,11 +437,14 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
     FP_TRY(run_mha_core(ctx, net->att_qk, net->att_v, tok, N, qk, vt, att, s));
     // mean over tokens commutes with out_proj (score_network.py:73-74)
     FP_TRY(launch_token_mean(att, N, 400, mean, s));
-    FP_TRY(launch_small_linear(mean, net->att_out.w, net->att_out.b, N, 512, 512, d_feats, s));
+    FP_TRY(launch_small_linear(mean, net->att_out.w, net->att_out.b, N, 512, 512, d_feats + (size_t)s0 * 512, s));
     return FP_OK;
   };
-  int rc = body();
-  ctx->arena.off = mark;
+  int rc = FP_OK;
+  for (int s0 = 0; s0 < NT && rc == FP_OK; s0 += CH) {
+    rc = body(s0, std::min(CH, NT - s0));
+    ctx->arena.off = mark;
+  }
   return rc;
 }
 
