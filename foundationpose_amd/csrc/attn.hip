@@ -185,13 +185,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // LayerNorm over 512 features, one wave per row (8 values per lane), fp32 in -> fp16 out.
-__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gam,
+__device__ __forceinline__ void load8(const float *p, float *v) {
+  const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const f16 *p, float *v) {
+  const half8 h = *reinterpret_cast<const half8 *>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI *__restrict__ x, const float *__restrict__ gam,
                                                         const float *__restrict__ bet, int M, f16 *__restrict__ out) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  const float4 a = *reinterpret_cast<const float4 *>(x + (size_t)row * 512 + lane * 8);
-  const float4 b = *reinterpret_cast<const float4 *>(x + (size_t)row * 512 + lane * 8 + 4);
-  float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  float v[8];
+  load8(x + (size_t)row * 512 + lane * 8, v);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += v[i];
@@ -211,14 +221,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s) {
   if (M == 0) return FP_OK;
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, M, out);
+  hipLaunchKernelGGL(layernorm_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, M, out);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+int launch_layernorm_h(const f16 *x, const float *g, const float *b, int M, f16 *out, hipStream_t s) {
+  if (M == 0) return FP_OK;
+  hipLaunchKernelGGL(layernorm_kernel<f16>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, M, out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
 
 // Final LayerNorm + mean over the T tokens of one hypothesis + Linear(512 -> out_dim<=6):
 // mean_t(Linear(LN(x_t))) == Linear(mean_t LN(x_t))  (refine_network.py:90-91).
-__global__ __launch_bounds__(256) void ln_mean_head_kernel(const float *__restrict__ x, const float *__restrict__ gam,
+template <typename TI>
+__global__ __launch_bounds__(256) void ln_mean_head_kernel(const TI *__restrict__ x, const float *__restrict__ gam,
                                                            const float *__restrict__ bet, int T, const float *__restrict__ hw,
                                                            const float *__restrict__ hb, int out_dim, float *__restrict__ out) {
   __shared__ float part[4][512];
@@ -226,10 +244,8 @@ __global__ __launch_bounds__(256) void ln_mean_head_kernel(const float *__restri
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int t = wave; t < T; t += 4) {
-    const float *xr = x + ((size_t)b * T + t) * 512 + lane * 8;
-    const float4 a = *reinterpret_cast<const float4 *>(xr);
-    const float4 c = *reinterpret_cast<const float4 *>(xr + 4);
-    float v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+    float v[8];
+    load8(x + ((size_t)b * T + t) * 512 + lane * 8, v);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += v[i];
@@ -266,7 +282,15 @@ __global__ __launch_bounds__(256) void ln_mean_head_kernel(const float *__restri
 int launch_ln_mean_head(const float *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb, int out_dim,
                         float *out, hipStream_t s) {
   if (Bn == 0) return FP_OK;
-  hipLaunchKernelGGL(ln_mean_head_kernel, dim3(Bn), dim3(256), 0, s, x, g, b, T, hw, hb, out_dim, out);
+  hipLaunchKernelGGL(ln_mean_head_kernel<float>, dim3(Bn), dim3(256), 0, s, x, g, b, T, hw, hb, out_dim, out);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+int launch_ln_mean_head_h(const f16 *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb, int out_dim,
+                          float *out, hipStream_t s) {
+  if (Bn == 0) return FP_OK;
+  hipLaunchKernelGGL(ln_mean_head_kernel<f16>, dim3(Bn), dim3(256), 0, s, x, g, b, T, hw, hb, out_dim, out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -201,7 +201,8 @@ __device__ __forceinline__ void glds16c(const f16 *g, f16 *l) {
 template <int BM, int KW, bool CIN8>
 __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f16 *__restrict__ zero_page) {
   constexpr int XH = C2_BN * C2_BK, WH = BM * C2_BK;      // halfs per stage
-  __shared__ __attribute__((aligned(16))) f16 smem[2 * (XH + WH)];
+  constexpr int SLD = BM + 8;                              // halfs per staged output row
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   constexpr int WM = BM / 2, MT = WM / 32, NT = 4;
@@ -300,7 +301,77 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     }
   }
 
-  // ---- epilogue (same lane ownership as v1) ----
+  // ---- epilogue, fp16 NHWC: residual staged through LDS, fp32 math, LDS transpose, 16-byte row stores ----
+  if (p.out_mode == 0) {
+    __syncthreads();
+    f16 *stage = smem;
+    constexpr int CPR = BM / 8;           // 16-byte chunks per staged row
+    constexpr int NCH = C2_BN * CPR / 256;
+    if (p.res) {
+#pragma unroll 4
+      for (int i = 0; i < NCH; ++i) {
+        const int idx = tid + 256 * i, px = idx / CPR, c16 = idx % CPR;
+        const int m = m0 + px;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m < p.M) v = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
+        *reinterpret_cast<uint4 *>(&stage[px * SLD + c16 * 8]) = v;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int pxl = wn * 128 + j * 32 + lr;
+      int prow = 0;
+      if (p.post_add) prow = min(m0 + pxl, p.M - 1) % p.post_period;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int col = wm * WM + i * 32 + rg * 8 + lh * 4;
+          const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + col);
+          float v[4] = {acc[i][j][rg * 4 + 0] + bv.x, acc[i][j][rg * 4 + 1] + bv.y, acc[i][j][rg * 4 + 2] + bv.z,
+                        acc[i][j][rg * 4 + 3] + bv.w};
+          f16 *sp = &stage[pxl * SLD + col];
+          if (p.res) {
+            half4 rv = *reinterpret_cast<const half4 *>(sp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (p.post_add) {
+            const float4 pv = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + col);
+            v[0] += pv.x;
+            v[1] += pv.y;
+            v[2] += pv.z;
+            v[3] += pv.w;
+          }
+          half4 hv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
+          *reinterpret_cast<half4 *>(sp) = hv;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < NCH; ++i) {
+      const int idx = tid + 256 * i, px = idx / CPR, c16 = idx % CPR;
+      const int m = m0 + px;
+      if (m < p.M) {
+        const bool hi = m >= p.split_m;
+        const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+        const int coff = hi ? p.coff_hi : 0;
+        *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) =
+            *reinterpret_cast<const uint4 *>(&stage[px * SLD + c16 * 8]);
+      }
+    }
+    return;
+  }
+
+  // ---- epilogue, other output modes (fp32 NHWC, transposed V): direct stores ----
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int m = m0 + wn * 128 + j * 32 + lr;
@@ -364,7 +435,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
 template <int BM, int KW, bool CIN8>
 static int launch_two(const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
   dim3 grid((a.M + C2_BN - 1) / C2_BN, a.Cout / BM);
-  hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8>), grid, dim3(256), 0, s, a, zero_page);
+  constexpr int main_b = 2 * (C2_BN * C2_BK + BM * C2_BK) * 2, epi_b = C2_BN * (BM + 8) * 2;
+  constexpr int lds = main_b > epi_b ? main_b : epi_b;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv_igemm2_kernel<BM, KW, CIN8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  FP_REQUIRE(a.out_mode != 0 || (a.out_ld % 8 == 0 && a.coff_hi % 8 == 0), "conv: out_ld/coff must be multiples of 8 for fp16 output");
+  hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8>), grid, dim3(256), lds, s, a, zero_page);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -388,7 +388,7 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     TAKE(qk, f16, (size_t)M * 1024);
     TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
     TAKE(att, f16, (size_t)M * 512);
-    TAKE(y32, float, (size_t)M * 512);
+    TAKE(y16, f16, (size_t)M * 512);   // pre-LayerNorm sums, fp16 like the reference's autocast path
     TAKE(x1, f16, (size_t)M * 512);
     TAKE(ff, f16, (size_t)M * 512);
     float *outs[2] = {d_trans + (size_t)s0 * 3, d_rot + (size_t)s0 * net->heads[1].out_dim};
@@ -396,11 +396,11 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
       const HeadW &H = net->heads[h];
       FP_TRY(run_mha_core(ctx, H.qk, H.v, tok, N, qk, vt, att, s));
       Conv2dCall c;
-      c = Conv2dCall{att, M, 1, 1, &H.out}; c.relu = 0; c.res = tok; c.out = y32; c.out_mode = 1; FP_TRY(run_conv(ctx, c, s));
-      FP_TRY(launch_layernorm(y32, H.ln1g, H.ln1b, M, x1, s));
+      c = Conv2dCall{att, M, 1, 1, &H.out}; c.relu = 0; c.res = tok; c.out = y16; FP_TRY(run_conv(ctx, c, s));
+      FP_TRY(launch_layernorm_h(y16, H.ln1g, H.ln1b, M, x1, s));
       c = Conv2dCall{x1, M, 1, 1, &H.ff1}; c.relu = 1; c.out = ff; FP_TRY(run_conv(ctx, c, s));
-      c = Conv2dCall{ff, M, 1, 1, &H.ff2}; c.relu = 0; c.res = x1; c.out = y32; c.out_mode = 1; FP_TRY(run_conv(ctx, c, s));
-      FP_TRY(launch_ln_mean_head(y32, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], s));
+      c = Conv2dCall{ff, M, 1, 1, &H.ff2}; c.relu = 0; c.res = x1; c.out = y16; FP_TRY(run_conv(ctx, c, s));
+      FP_TRY(launch_ln_mean_head_h(y16, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], s));
     }
     return FP_OK;
   };
