@@ -93,6 +93,18 @@ def step(est, objects, world, rank):
   return results
 
 
+def pmc_traffic():
+  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+  (profiles/r01_halo_traffic.json; FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected
+  as MI355X_MICROARCH.md prescribes).  None when no such profile has been committed."""
+  path = os.path.join(REPO, 'profiles', 'r01_halo_traffic.json')
+  try:
+    with open(path) as f:
+      return json.load(f)
+  except OSError:
+    return None
+
+
 def cpu_baseline():
   """The CPU oracle timed on this host's cores on a bounded sample of the same workload."""
   from tests import util
@@ -155,7 +167,7 @@ def main():
   barrier()
   dt = time.perf_counter() - t0
   ctx.prof_enable(False)
-  conv = ctx.prof_read('conv3x3')
+  conv = ctx.prof_read('conv3x3_halo')
   tmax = torch.tensor([dt], device=device, dtype=torch.float64)
   if world > 1:
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -173,9 +185,10 @@ def main():
                              '480x640 RGB-D frame; one such object per GPU, hypotheses sharded over all ranks',
                  'hypotheses_per_object': N_HYP, 'objects': world, 'est_refine_iter': ITER, 'parallelism': f'hyp-shard x{world}',
                  'weights': 'seeded random (reference state_dict layout)'},
-      'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (3x3 implicit-GEMM convolutions)', 'achieved': achieved,
-                   'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F16_TFLOPS,
-                   'avg_launch_ms': conv['total_ms'] / max(conv['launches'], 1), 'launches': conv['launches'], 'traffic': None},
+      'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_halo_kernel (3x3 stride-1 convolutions: 93 % of the conv FLOPs)',
+                   'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F16_TFLOPS,
+                   'avg_launch_ms': conv['total_ms'] / max(conv['launches'], 1), 'launches': conv['launches'],
+                   'flops_per_launch': conv['flops'] / max(conv['launches'], 1), 'traffic': pmc_traffic()},
     }
     if not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()

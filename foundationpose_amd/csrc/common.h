@@ -113,6 +113,17 @@ struct ProfScope {
   }
 };
 
+// XCD-aware tile order (MI355X: 8 XCDs with private L2s, workgroups dealt round-robin): workgroup `id` of `nwg`
+// gets logical tile index L such that each XCD walks a CONTIGUOUS range of L; neighbouring tiles (which share
+// halo rows / the same pixels for another cout tile) then hit the same L2.  Bijective for any nwg.  Speed only.
+#ifdef __HIPCC__
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+  const int xcd = id & 7, slot = id >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+#endif
+
 // ---- kernel launchers implemented in the .hip files ----
 struct ConvArgs {
   const f16 *in;

@@ -208,7 +208,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
   constexpr int WM = BM / 2, MT = WM / 32, NT = 4;
   constexpr int WQ = BM / 64;                              // weight DMA instructions per wave per stage
   const int lr = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * C2_BN, c0 = blockIdx.y * BM;
+  const int n_ct = p.Cout / BM;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (L / n_ct) * C2_BN, c0 = (L % n_ct) * BM;
   const int HoWo = p.Ho * p.Wo;
   const int ntaps = p.KH * p.KW;
 
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
 
 template <int BM, int KW, bool CIN8>
 static int launch_two(const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
-  dim3 grid((a.M + C2_BN - 1) / C2_BN, a.Cout / BM);
+  dim3 grid(((a.M + C2_BN - 1) / C2_BN) * (a.Cout / BM));
   constexpr int main_b = 2 * (C2_BN * C2_BK + BM * C2_BK) * 2, epi_b = C2_BN * (BM + 8) * 2;
   constexpr int lds = main_b > epi_b ? main_b : epi_b;
   static bool attr_set = false;
@@ -468,9 +470,10 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   FP_REQUIRE(a.out_ld % 4 == 0 && a.coff_hi % 4 == 0, "conv: out_ld/coff must be multiples of 4");
   if (a.M == 0) return FP_OK;
   const double flops = 2.0 * (double)a.M * a.Cout * a.KH * a.KW * (a.Cin == 8 ? 6 : a.Cin);
-  const char *cls = (a.KW == 3) ? "conv3x3" : (a.KW == 7 ? "conv7x7" : "linear");
+  const bool halo = conv_halo_supported(a);
+  const char *cls = halo ? "conv3x3_halo" : (a.KW == 3) ? "conv3x3_s2" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
-  if (conv_halo_supported(a)) return launch_conv_halo(a, s);
+  if (halo) return launch_conv_halo(a, s);
   const bool bm128 = (a.Cout % 128 == 0);
   const f16 *zp = (const f16 *)ctx->zero_page;
   if (a.Cin == 8) {

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * HL_TM, c0 = blockIdx.y * HL_BM;
+  const int n_ct = p.Cout / HL_BM;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);          // 1-D grid; consecutive L = cout tiles of one pixel tile, then the next pixel tile
+  const int m0 = (L / n_ct) * HL_TM, c0 = (L % n_ct) * HL_BM;
   const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by slot 0
   const int mlast = min(m0 + HL_TM - 1, p.M - 1);
   const int NS = mlast / W + 1 - GR0 + 1;           // slots in use
@@ -272,7 +274,7 @@ static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
     FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     attr_set = true;
   }
-  dim3 grid((a.M + HL_TM - 1) / HL_TM, a.Cout / HL_BM);
+  dim3 grid(((a.M + HL_TM - 1) / HL_TM) * (a.Cout / HL_BM));
   hipLaunchKernelGGL((conv3x3_halo_kernel<W, NWN>), grid, dim3(128 * NWN), C::LDS_BYTES, s, a);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;

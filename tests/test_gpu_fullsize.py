@@ -1,0 +1,138 @@
+"""GPU, BASELINE.json full sizes (252 hypotheses, est_refine_iter=5; 4 objects x 252): size-independent
+properties the domain offers, since the CPU oracle needs minutes at this size -
+  * per-hypothesis independence: batch-split invariance and permutation equivariance, BIT-exact
+    (every output element has a fixed accumulation order, independent of tiling and batch position);
+  * determinism (visibility is resolved by integer keys, no float atomics anywhere);
+  * the 8-way sharded schedule of bench.py / dist.py reproduces the unsharded result bit for bit;
+  * per-object grouping of the score tail (configs[3]: 4 objects x 252);
+  * refined poses stay rigid transforms; scores are sorted; argmax is a valid hypothesis index."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+N = 252
+
+
+@pytest.fixture(scope='module')
+def env():
+  from foundationpose_amd import _lib, synthetic as S
+  from foundationpose_amd.config import REFINE_DEFAULT, SCORE_DEFAULT
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+  from foundationpose_amd.predict_score import ScorePredictor
+  sc = util.scene(0)
+  refiner = PoseRefinePredictor(state_dict=S.make_refine_state_dict(0), cfg=REFINE_DEFAULT)
+  scorer = ScorePredictor(state_dict=S.make_score_state_dict(1), cfg=SCORE_DEFAULT)
+  refiner.ctx.reserve(N)
+  from oracle import geometry as G
+  depth = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+  return dict(sc=sc, refiner=refiner, scorer=scorer, depth=depth, xyz=G.depth2xyzmap(depth, sc['K']), mt=util.to_dev(sc['mt']),
+              poses=torch.from_numpy(util.hypotheses(sc, N)).cuda(), lib=_lib)
+
+
+def _net_inputs(n, seed):
+  g = torch.Generator(device='cuda').manual_seed(seed)
+  x = torch.zeros((2 * n, 160, 160, 8), dtype=torch.float16, device='cuda')
+  x[..., :3] = torch.rand((2 * n, 160, 160, 3), device='cuda', generator=g).half()
+  xyz = torch.randn((2 * n, 160, 160, 3), device='cuda', generator=g) * 0.5
+  xyz[torch.rand((2 * n, 160, 160, 1), device='cuda', generator=g).expand_as(xyz) < 0.4] = 0
+  x[..., 3:6] = xyz.half()
+  return x
+
+
+def _refine(env, x, n):
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  r = env['refiner']
+  trans = torch.empty((n, 3), device='cuda')
+  rot = torch.empty((n, 3), device='cuda')
+  check(lib().fp_refine_forward(r.ctx.handle, r.model.handle, ptr(x), n, ptr(trans), ptr(rot), stream_ptr()))
+  return trans, rot
+
+
+def test_refine_net_batch_split_permutation_determinism(env):
+  x = _net_inputs(N, 5)
+  t_all, r_all = _refine(env, x, N)
+  t_again, r_again = _refine(env, x, N)
+  assert torch.equal(t_all, t_again) and torch.equal(r_all, r_again)                  # determinism
+  assert float(t_all.std(0).min()) > 0 and torch.isfinite(t_all).all() and torch.isfinite(r_all).all()
+  # split 252 = 100 + 152 (different tile boundaries): A|B halves re-packed per part
+  for a, b in ((0, 100), (100, N)):
+    part = torch.cat([x[a:b], x[N + a:N + b]], 0).contiguous()
+    t_p, r_p = _refine(env, part, b - a)
+    assert torch.equal(t_p, t_all[a:b]) and torch.equal(r_p, r_all[a:b])
+  perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).cuda()
+  xp = torch.cat([x[:N][perm], x[N:][perm]], 0).contiguous()
+  t_q, r_q = _refine(env, xp, N)
+  assert torch.equal(t_q, t_all[perm]) and torch.equal(r_q, r_all[perm])
+
+
+def test_register_core_252_iter5_and_8way_sharding(env):
+  """configs[1] + configs[2]: refine x5 + features + tail on 252 hypotheses; then the same with the
+  hypotheses cut into the 8 shards bench.py/dist.py use (32 x7 + 28), processed one after the other on
+  this GPU, gathered, and scored - must equal the unsharded run bit for bit, including the argmax."""
+  from foundationpose_amd.dist import pack_rows, shard_ranges, unpack_rows
+  sc, refiner, scorer = env['sc'], env['refiner'], env['scorer']
+  kw = dict(rgb=sc['rgb'], depth=env['depth'], K=sc['K'], mesh_tensors=env['mt'], mesh_diameter=sc['diameter'])
+  refined, _ = refiner.predict(ob_in_cams=env['poses'], xyz_map=env['xyz'], iteration=5, **kw)
+  feats = scorer.extract_features(ob_in_cams=refined, **kw)
+  logits, am = scorer.score_tail(feats, L=N)
+  R = refined[:, :3, :3]
+  eye = torch.eye(3, device='cuda')[None]
+  assert float((R @ R.transpose(1, 2) - eye).abs().max()) < 5e-5      # five chained updates keep R orthonormal
+  assert float((torch.linalg.det(R) - 1).abs().max()) < 5e-5
+  assert torch.equal(refined[:, 3], torch.tensor([0., 0., 0., 1.], device='cuda').expand(N, 4))
+  assert float((refined[:, :3, 3] - env['poses'][:, :3, 3]).abs().max()) < 0.2   # refinement steps stay bounded
+  assert 0 <= int(am[0]) < N and int(am[0]) == int(logits.argmax())
+  world, shard = 8, 32
+  blocks = []
+  for a, b in shard_ranges(N, world):
+    p, _ = refiner.predict(ob_in_cams=env['poses'][a:b], xyz_map=env['xyz'], iteration=5, **kw)
+    f = scorer.extract_features(ob_in_cams=p, **kw)
+    blocks.append(pack_rows(f, p, shard))
+  f2, p2 = unpack_rows(torch.cat(blocks, 0), N, world)
+  assert torch.equal(p2, refined) and torch.equal(f2, feats)
+  logits2, am2 = scorer.score_tail(f2, L=N)
+  assert torch.equal(logits2, logits) and int(am2[0]) == int(am[0])
+
+
+def test_score_tail_groups_4x252(env):
+  """configs[3]: 4 concurrent objects x 252 hypotheses -> per-object logits / argmax equal the 4 single-object calls."""
+  scorer = env['scorer']
+  g = torch.Generator(device='cuda').manual_seed(9)
+  feats = torch.randn((4 * N, 512), device='cuda', generator=g)
+  logits, am = scorer.score_tail(feats, L=N)
+  assert logits.shape == (4, N) and am.shape == (4,)
+  for o in range(4):
+    lo, ao = scorer.score_tail(feats[o * N:(o + 1) * N].contiguous(), L=N)
+    assert torch.equal(lo[0], logits[o]) and int(ao[0]) == int(am[o]) == int(logits[o].argmax())
+  # permuting the hypotheses of one object permutes its logits (set-equivariance of att_cross), within fp32 summation noise
+  perm = torch.randperm(N, generator=torch.Generator().manual_seed(2)).cuda()
+  lp, _ = scorer.score_tail(feats[:N][perm].contiguous(), L=N)
+  np.testing.assert_allclose(lp[0].cpu().numpy(), logits[0][perm].cpu().numpy(), atol=2e-6)
+
+
+def test_renderer_determinism_and_pose_locality(env):
+  """252 crops rendered twice are identical; changing one pose changes only that crop."""
+  from foundationpose_amd._lib import check, k_ptr, lib, ptr, stream_ptr
+  sc, ctx = env['sc'], env['refiner'].ctx
+  dm = env['lib'].device_mesh(ctx, env['mt'])
+  poses = env['poses'].clone()
+  Kd, Kp = k_ptr(sc['K'])
+  tf = torch.empty((N, 3, 3), device='cuda'); bbox = torch.empty((N, 4), device='cuda')
+
+  def render(p):
+    out = torch.empty((N, 160, 160, 8), dtype=torch.float16, device='cuda')
+    check(lib().fp_crop_window_tf(ctx.handle, ptr(p), N, Kp, 1.2, sc['diameter'], 160, 160, ptr(tf), ptr(bbox), stream_ptr()))
+    check(lib().fp_render_net(ctx.handle, dm.handle, ptr(p), N, Kp, 480, 640, ptr(bbox), 160, 160, sc['diameter'], 1, 0.001, ptr(out), stream_ptr()))
+    return out
+  a, b = render(poses), render(poses)
+  assert torch.equal(a, b)
+  cov = (a[..., 5] != 0).float().mean(dim=(1, 2))
+  assert float(cov.min()) > 0.05                         # every hypothesis shows the object (end-on views cover ~10 %)
+  poses[17, :3, 3] += torch.tensor([0.004, -0.003, 0.01], device='cuda')
+  c = render(poses)
+  same = (a == c).flatten(1).all(1)
+  assert not bool(same[17]) and bool(same[torch.arange(N, device='cuda') != 17].all())
