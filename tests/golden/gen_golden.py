@@ -170,6 +170,23 @@ def main():
   sel = bp.select_by_indices(torch.tensor([2, 0]))
   out['bpd_rgbAs'] = sel.rgbAs.numpy(); out['bpd_poseA'] = sel.poseA.numpy()
 
+  # ---- src/transform.py PoseTransformer (pure python) ---------------------------------------------
+  sys.path.insert(0, os.path.join(REF, 'src'))
+  import contextlib, io
+  from transform import PoseTransformer as RefPT
+  mats = []
+  for i in range(6):
+    M = np.eye(4); M[:3, :3] = S.random_rotation(rs); M[:3, 3] = rs.randn(3)
+    mats.append(M)
+  for sgn in (1.0, -1.0):     # gimbal lock: R[2,0] = -+1
+    c, s_ = np.cos(0.7), np.sin(0.7)
+    M = np.eye(4); M[:3, :3] = np.array([[0, -s_, c * sgn], [0, c, s_ * sgn], [-sgn, 0, 0]]); M[:3, 3] = [0.1, -0.2, 0.9]
+    mats.append(M)
+  out['pt_mats'] = np.asarray(mats)
+  with contextlib.redirect_stdout(io.StringIO()):
+    out['pt_inch_deg'] = np.asarray([RefPT().transform_pose(M) for M in mats])
+    out['pt_m_rad'] = np.asarray([RefPT(to_inches=False, to_degrees=False).transform_pose(M) for M in mats])
+
   path = os.path.join(HERE, 'reference_outputs.npz')
   np.savez_compressed(path, **out)
   print('wrote', path, {k: np.asarray(v).shape for k, v in out.items()})

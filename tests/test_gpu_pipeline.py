@@ -216,3 +216,27 @@ def test_register_through_dist_group_world1(estimators):
     est.dist_group = None
     est.rot_grid = full
     dist.destroy_process_group()
+
+
+def test_readme_pipeline_protocol_end_to_end(estimators):
+  """readme.md:122-179: Pipeline + FoundationPoseEstimator + PoseTransformer -> data.pose_6d; the second
+  frame (no mask) goes through track_one."""
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.pipeline import FoundationPoseEstimator, Pipeline, PipelineData, PoseTransformer, Processor
+  sc, est = estimators['sc'], estimators['est']
+
+  class Frame(Processor):
+    def __init__(self, with_mask): self.with_mask = with_mask
+    def process(self, data):
+      data.rgb, data.depth, data.K = sc['rgb'], sc['depth'], sc['K']
+      data.mask = sc['mask'] if self.with_mask else None
+      return data
+  stage = FoundationPoseEstimator(mesh=S.make_mustard_mesh(seed=0), K=sc['K'], est_refine_iter=1, track_refine_iter=1,
+                                  scorer=est.scorer, refiner=est.refiner)
+  np.random.seed(0)
+  pipe = Pipeline('demo', stop_on_error=True).add_processor(Frame(True)).add_processor(stage).add_processor(PoseTransformer())
+  out = pipe.run(PipelineData())
+  assert not out.errors and out.pose.shape == (4, 4) and len(out.pose_6d) == 6 and np.isfinite(out.pose_6d).all()
+  pipe.processors[0] = Frame(False)
+  out2 = pipe.run(PipelineData())
+  assert not out2.errors and np.abs(out2.pose - out.pose).max() < 0.1

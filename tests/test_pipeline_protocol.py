@@ -1,0 +1,56 @@
+"""CPU: the readme's Processor / Pipeline protocol, PoseTransformer against the reference's own
+src/transform.py outputs (golden), OBJ round trip."""
+import numpy as np
+import pytest
+
+from foundationpose_amd import synthetic as S
+from foundationpose_amd.mesh_io import load_intrinsics, load_obj, save_obj
+from foundationpose_amd.pipeline import Pipeline, PipelineData, PoseTransformer, Processor
+
+
+def test_pose_transformer_matches_reference(golden):
+  for M, a, b in zip(golden['pt_mats'], golden['pt_inch_deg'], golden['pt_m_rad']):
+    np.testing.assert_allclose(PoseTransformer().transform_pose(M), a, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(PoseTransformer(to_inches=False, to_degrees=False).transform_pose(M), b, rtol=0, atol=1e-12)
+
+
+class _Add(Processor):
+  def __init__(self, k): self.k = k
+  def process(self, data):
+    data.trace = getattr(data, 'trace', []) + [self.k]
+    return data
+
+
+class _Boom(Processor):
+  def process(self, data):
+    raise ValueError('boom')
+
+
+def test_pipeline_order_and_error_policy():
+  out = Pipeline('p').add_processor(_Add(1)).add_processor(_Boom()).add_processor(_Add(2)).run(PipelineData())
+  assert out.trace == [1, 2] and [n for n, _ in out.errors] == ['_Boom']
+  out = Pipeline('p', stop_on_error=True).add_processor(_Add(1)).add_processor(_Boom()).add_processor(_Add(2)).run()
+  assert out.trace == [1] and len(out.errors) == 1
+  with pytest.raises(TypeError):
+    Pipeline().add_processor(object())
+  d = PipelineData(pose=np.eye(4))
+  assert Pipeline().add_processor(PoseTransformer()).run(d).pose_6d == (0.0, 0.0, 0.0, 0.0, -0.0, 0.0)
+
+
+def test_obj_roundtrip_and_intrinsics(tmp_path):
+  mesh = S.make_mustard_mesh(seed=3, n_theta=12, n_z=8)
+  p = tmp_path / 'm.obj'
+  save_obj(mesh, str(p))
+  back = load_obj(str(p))
+  np.testing.assert_allclose(back.vertices, mesh.vertices, rtol=1e-8)
+  np.testing.assert_array_equal(back.faces, mesh.faces)
+  assert np.abs(back.visual.vertex_colors[:, :3].astype(int) - mesh.visual.vertex_colors[:, :3].astype(int)).max() <= 1
+  np.testing.assert_allclose(back.vertex_normals, mesh.vertex_normals, atol=1e-6)
+  (tmp_path / 'q.obj').write_text('v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\nf -4/1 -3/2 -2/3\n')
+  quad = load_obj(str(tmp_path / 'q.obj'), texture_image=np.zeros((2, 2, 3), np.uint8))
+  assert quad.faces.shape == (3, 3) and quad.visual.uv.shape == (4, 2)
+  (tmp_path / 'k.txt').write_text('1066.778 0 312.9869\n0 1067.487 241.3109\n0 0 1\n')
+  np.testing.assert_allclose(load_intrinsics(str(tmp_path / 'k.txt')), S.YCB_K)
+  (tmp_path / 'bad.obj').write_text('# nothing\n')
+  with pytest.raises(ValueError):
+    load_obj(str(tmp_path / 'bad.obj'))
