@@ -25,8 +25,10 @@
 __global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__restrict__ qk, const f16 *__restrict__ vt, int T,
                                                                f16 *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
-  const int qb = blockIdx.x;  // query block (80 queries)
-  const int h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, XCD-aware order: the query blocks of one (hypothesis, head) share K and V -> same XCD L2
+  const int nqb = (T + AT_WAVES * 16 - 1) / (AT_WAVES * 16);
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = L % nqb, h = (L / nqb) & 3, b = L / (nqb * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int ntile = (T + 15) / 16;  // key tiles (25)
@@ -170,7 +172,7 @@ int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f1
   size_t lds_k = (size_t)ntile * 16 * AT_KLD * 2, lds_v = (size_t)AT_DH * AT_VLD * 2;
   size_t lds = lds_k > lds_v ? lds_k : lds_v;
   FP_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid((T + AT_WAVES * 16 - 1) / (AT_WAVES * 16), 4, B);
+  dim3 grid(((T + AT_WAVES * 16 - 1) / (AT_WAVES * 16)) * 4 * B);
   ProfScope ps(ctx, s, "attention", 4.0 * B * 4 * (double)T * T * AT_DH);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(AT_THREADS), lds, s, qk, vt, T, out);
   FP_CHECK_HIP(hipGetLastError());
@@ -235,15 +237,17 @@ int launch_layernorm_h(const f16 *x, const float *g, const float *b, int M, f16 
 
 // Final LayerNorm + mean over the T tokens of one hypothesis + Linear(512 -> out_dim<=6):
 // mean_t(Linear(LN(x_t))) == Linear(mean_t LN(x_t))  (refine_network.py:90-91).
+// Two launches so that 252 hypotheses fill the chip: (1) LNP_SPLIT workgroups per hypothesis sum the
+// normalised rows of their token range -> partial[b][part][512]; (2) one small workgroup per hypothesis
+// adds the partials in a fixed order (deterministic), applies gamma/beta and the output Linear.
+#define LNP_SPLIT 8
 template <typename TI>
-__global__ __launch_bounds__(256) void ln_mean_head_kernel(const TI *__restrict__ x, const float *__restrict__ gam,
-                                                           const float *__restrict__ bet, int T, const float *__restrict__ hw,
-                                                           const float *__restrict__ hb, int out_dim, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void ln_partial_kernel(const TI *__restrict__ x, int T, float *__restrict__ partial) {
   __shared__ float part[4][512];
-  __shared__ float meanv[512];
-  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x / LNP_SPLIT, q = blockIdx.x % LNP_SPLIT, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per = (T + LNP_SPLIT - 1) / LNP_SPLIT, t0 = q * per, t1 = min(T, t0 + per);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int t = wave; t < T; t += 4) {
+  for (int t = t0 + wave; t < t1; t += 4) {
     float v[8];
     load8(x + ((size_t)b * T + t) * 512 + lane * 8, v);
     float s = 0.f;
@@ -263,34 +267,45 @@ __global__ __launch_bounds__(256) void ln_mean_head_kernel(const TI *__restrict_
 #pragma unroll
   for (int i = 0; i < 8; ++i) part[wave][lane * 8 + i] = acc[i];
   __syncthreads();
-  for (int f = threadIdx.x; f < 512; f += 256) {
-    float m = (part[0][f] + part[1][f]) + (part[2][f] + part[3][f]);
+  for (int f = threadIdx.x; f < 512; f += 256)
+    partial[((size_t)b * LNP_SPLIT + q) * 512 + f] = (part[0][f] + part[1][f]) + (part[2][f] + part[3][f]);
+}
+
+__global__ __launch_bounds__(128) void mean_head_kernel(const float *__restrict__ partial, const float *__restrict__ gam,
+                                                        const float *__restrict__ bet, int T, const float *__restrict__ hw,
+                                                        const float *__restrict__ hb, int out_dim, float *__restrict__ out) {
+  __shared__ float meanv[512];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int f = threadIdx.x; f < 512; f += 128) {
+    float m = 0.f;
+#pragma unroll
+    for (int q = 0; q < LNP_SPLIT; ++q) m += partial[((size_t)b * LNP_SPLIT + q) * 512 + f];
     meanv[f] = m * (1.f / (float)T) * gam[f] + bet[f];
   }
   __syncthreads();
-  if (wave < 2) {
-    for (int o = wave; o < out_dim; o += 2) {
-      float s = 0.f;
+  for (int o = wave; o < out_dim; o += 2) {
+    float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) s += meanv[lane * 8 + i] * hw[(size_t)o * 512 + lane * 8 + i];
-      s = wave_sum(s);
-      if (lane == 0) out[(size_t)b * out_dim + o] = s + hb[o];
-    }
+    for (int i = 0; i < 8; ++i) s += meanv[lane * 8 + i] * hw[(size_t)o * 512 + lane * 8 + i];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)b * out_dim + o] = s + hb[o];
   }
 }
 
 int launch_ln_mean_head(const float *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb, int out_dim,
-                        float *out, hipStream_t s) {
+                        float *out, float *scratch, hipStream_t s) {
   if (Bn == 0) return FP_OK;
-  hipLaunchKernelGGL(ln_mean_head_kernel<float>, dim3(Bn), dim3(256), 0, s, x, g, b, T, hw, hb, out_dim, out);
+  hipLaunchKernelGGL(ln_partial_kernel<float>, dim3(Bn * LNP_SPLIT), dim3(256), 0, s, x, T, scratch);
+  hipLaunchKernelGGL(mean_head_kernel, dim3(Bn), dim3(128), 0, s, scratch, g, b, T, hw, hb, out_dim, out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
 
 int launch_ln_mean_head_h(const f16 *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb, int out_dim,
-                          float *out, hipStream_t s) {
+                          float *out, float *scratch, hipStream_t s) {
   if (Bn == 0) return FP_OK;
-  hipLaunchKernelGGL(ln_mean_head_kernel<f16>, dim3(Bn), dim3(256), 0, s, x, g, b, T, hw, hb, out_dim, out);
+  hipLaunchKernelGGL(ln_partial_kernel<f16>, dim3(Bn * LNP_SPLIT), dim3(256), 0, s, x, T, scratch);
+  hipLaunchKernelGGL(mean_head_kernel, dim3(Bn), dim3(128), 0, s, scratch, g, b, T, hw, hb, out_dim, out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -142,9 +142,9 @@ int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f1
 int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
 int launch_layernorm_h(const f16 *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
 int launch_ln_mean_head_h(const f16 *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
-                          int out_dim, float *out, hipStream_t s);
+                          int out_dim, float *out, float *scratch /* Bn*8*512 */, hipStream_t s);
 int launch_ln_mean_head(const float *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
-                        int out_dim, float *out, hipStream_t s);
+                        int out_dim, float *out, float *scratch /* Bn*8*512 */, hipStream_t s);
 int launch_token_mean(const f16 *x, int Bn, int T, float *out, hipStream_t s);
 int launch_small_linear(const float *x, const float *w, const float *b, int M, int K, int N, float *out, hipStream_t s);
 int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s);

@@ -391,6 +391,7 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     TAKE(y16, f16, (size_t)M * 512);   // pre-LayerNorm sums, fp16 like the reference's autocast path
     TAKE(x1, f16, (size_t)M * 512);
     TAKE(ff, f16, (size_t)M * 512);
+    TAKE(lnpart, float, (size_t)N * 8 * 512);
     float *outs[2] = {d_trans + (size_t)s0 * 3, d_rot + (size_t)s0 * net->heads[1].out_dim};
     for (int h = 0; h < 2; ++h) {
       const HeadW &H = net->heads[h];
@@ -400,7 +401,7 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
       FP_TRY(launch_layernorm_h(y16, H.ln1g, H.ln1b, M, x1, s));
       c = Conv2dCall{x1, M, 1, 1, &H.ff1}; c.relu = 1; c.out = ff; FP_TRY(run_conv(ctx, c, s));
       c = Conv2dCall{ff, M, 1, 1, &H.ff2}; c.relu = 0; c.res = x1; c.out = y16; FP_TRY(run_conv(ctx, c, s));
-      FP_TRY(launch_ln_mean_head_h(y16, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], s));
+      FP_TRY(launch_ln_mean_head_h(y16, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], lnpart, s));
     }
     return FP_OK;
   };
