@@ -15,43 +15,54 @@
 #define AT_VLD 424   // halfs per Vt row in LDS (416 + 8 pad)  -> 848 B
 #define AT_MAXT 400
 
-// One workgroup = one (hypothesis, head, 80-query block); each wave owns 16 queries.
+// One workgroup = one (hypothesis, head, 160-query block); each of the 10 waves owns 16 queries.
+//   staging: K (400 x 128, 100 KB) and the low half of V^T (64 x 416, 52 KB) arrive by LDS-DMA
+//            (global_load_lds_dwordx4: every load of the tile in flight at once, no VGPRs); both images are
+//            lane-linear in LDS with the XOR swizzle applied on the SOURCE address (K: chunk ^ (key&15),
+//            V^T: chunk ^ ((d>>2)&3)) so the fragment reads are bank-conflict free.
 //   phase 1: S^T = K Q^T with v_mfma_f32_16x16x32_f16 (A = K tile from LDS, B = Q fragments held in
 //            registers) -> the lane owning query column q holds 4 keys per 16-key tile; the whole
 //            400-key row (100 fp32) stays in registers, softmax needs two xor-shuffles.
 //   phase 2: O = P V.  The S^T accumulator layout IS the A-operand layout of the next MFMA when two
 //            key tiles are paired per k-step with the k order (tile0: 4g+0..3, tile1: 4g+0..3); V is
-//            consumed from the transposed image [d][token] so its B fragments are two 8-byte reads.
+//            consumed from the transposed image so its B fragments are two 8-byte reads.  The high half
+//            of V^T is DMA'd over the (dead) K image while the low half is being multiplied.
+#define AT_VROW 416                    // halfs per V^T row (= AT_TP), 52 16-byte chunks
+#define AT_KBYTES (400 * 256)          // K image
+#define AT_VHALF (64 * AT_VROW * 2)    // one half of V^T
+
+__device__ __forceinline__ void at_glds16(const f16 *g, f16 *l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
 __global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__restrict__ qk, const f16 *__restrict__ vt, int T,
-                                                               f16 *__restrict__ out) {
+                                                               f16 *__restrict__ out, const f16 *__restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
+  f16 *ks = smem;                        // [400][128] swizzled; later V^T high half [64][416]
+  f16 *vlo = smem + AT_KBYTES / 2;       // V^T low half [64][416]
   // 1-D grid, XCD-aware order: the query blocks of one (hypothesis, head) share K and V -> same XCD L2
   const int nqb = (T + AT_WAVES * 16 - 1) / (AT_WAVES * 16);
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int qb = L % nqb, h = (L / nqb) & 3, b = L / (nqb * 4);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, g = lane >> 4;
   const int ntile = (T + 15) / 16;  // key tiles (25)
   const size_t rowbase = (size_t)b * T;
+  const f16 *vsrc = vt + ((size_t)b * 4 + h) * AT_DH * AT_TP;
 
-  // ---- stage K (T x 128) into LDS, zero-fill the tail rows of the last tile.  Loads are issued in batches
-  //      of 5 before the first ds_write so that their latencies overlap (a load->store loop serialises them) ----
-  const int kchunks = ntile * 16 * (AT_DH / 8);
-#pragma unroll 1
-  for (int c0 = tid; c0 < kchunks; c0 += AT_THREADS * 5) {
-    uint4 v[5];
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      const int c = c0 + u * AT_THREADS, key = c >> 4, ch = c & 15;
-      v[u] = make_uint4(0, 0, 0, 0);
-      if (c < kchunks && key < T) v[u] = *reinterpret_cast<const uint4 *>(qk + (rowbase + key) * 1024 + 512 + h * AT_DH + ch * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      const int c = c0 + u * AT_THREADS, key = c >> 4, ch = c & 15;
-      if (c < kchunks) *reinterpret_cast<uint4 *>(&smem[key * AT_KLD + ch * 8]) = v[u];
-    }
+  // ---- issue every K and V^T(low) DMA ----
+  for (int c0 = wave * 64; c0 < ntile * 256; c0 += AT_THREADS) {      // 16 chunks per key row
+    const int c = c0 + lane, key = c >> 4, chp = c & 15;
+    const f16 *src = key < T ? qk + (rowbase + key) * 1024 + 512 + h * AT_DH + ((chp ^ (key & 15)) * 8) : zero_page;
+    at_glds16(src, ks + (size_t)c0 * 8);
   }
+  auto vstage = [&](int half, f16 *dst) {
+    for (int c0 = wave * 64; c0 < 64 * 52; c0 += AT_THREADS) {         // 52 chunks per row, 64 rows = 3328 = 52 x 64
+      const int c = c0 + lane, dl = c / 52, chp = c - dl * 52, d = half * 64 + dl;
+      at_glds16(vsrc + (size_t)d * AT_TP + ((chp ^ ((d >> 2) & 3)) * 8), dst + (size_t)c0 * 8);
+    }
+  };
+  vstage(0, vlo);
   // ---- Q fragments: B operand, lane (q = lq, g) holds Q[q][32s + 8g .. +7] ----
   const int q = qb * (AT_WAVES * 16) + wave * 16 + lq;
   const bool qvalid = q < T;
@@ -62,7 +73,7 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__rest
     if (qvalid) v = *reinterpret_cast<const uint4 *>(qk + (rowbase + q) * 1024 + h * AT_DH + s * 32 + g * 8);
     qf[s] = *reinterpret_cast<half8 *>(&v);
   }
-  __syncthreads();
+  __syncthreads();   // hipcc drains vmcnt(0) before the barrier: K, V^T(low) and Q have landed
 
   // ---- phase 1: S^T tiles ----
   floatx4 st[26];
@@ -73,7 +84,7 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__rest
     if (t < ntile) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        half8 kf = *reinterpret_cast<const half8 *>(&smem[(t * 16 + lq) * AT_KLD + s * 32 + g * 8]);
+        half8 kf = *reinterpret_cast<const half8 *>(&ks[(t * 16 + lq) * 128 + (((s * 4 + g) ^ lq) * 8)]);
         st[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], st[t], 0, 0, 0);
       }
     }
@@ -103,52 +114,41 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__rest
   sum += __shfl_xor(sum, 16);
   sum += __shfl_xor(sum, 32);
   const float inv = 1.f / sum;
-  __syncthreads();  // everyone is done reading K from LDS
-
-  // ---- stage V^T (128 x 416) into LDS (batched loads, as for K) ----
-  const f16 *vsrc = vt + ((size_t)b * 4 + h) * AT_DH * AT_TP;
-  constexpr int VCH = AT_DH * (AT_TP / 8);
-#pragma unroll 1
-  for (int c0 = tid; c0 < VCH; c0 += AT_THREADS * 7) {
-    uint4 v[7];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int c = c0 + u * AT_THREADS;
-      v[u] = make_uint4(0, 0, 0, 0);
-      if (c < VCH) v[u] = *reinterpret_cast<const uint4 *>(vsrc + (size_t)c * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int c = c0 + u * AT_THREADS, d = c / (AT_TP / 8), ch = c - d * (AT_TP / 8);
-      if (c < VCH) *reinterpret_cast<uint4 *>(&smem[d * AT_VLD + ch * 8]) = v[u];
-    }
-  }
-  __syncthreads();
+  __syncthreads();  // everyone is done reading K
+  vstage(1, ks);    // V^T high half over the K image, in flight under phase 2a
 
   // ---- phase 2: O = P V, 13 k-steps of 32 keys (two key tiles each), 8 n-tiles of 16 dims ----
   floatx4 oacc[8];
 #pragma unroll
   for (int n = 0; n < 8; ++n) oacc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+  half8 pfr[13];
 #pragma unroll
-  for (int s = 0; s < 13; ++s) {
-    half8 pf;
+  for (int s = 0; s < 13; ++s)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      pf[r] = (f16)st[2 * s][r];
-      pf[4 + r] = (f16)st[2 * s + 1][r];
+      pfr[s][r] = (f16)st[2 * s][r];
+      pfr[s][4 + r] = (f16)st[2 * s + 1][r];
     }
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const f16 *vrow = &smem[(n * 16 + lq) * AT_VLD + g * 4];
-      half4 v0 = *reinterpret_cast<const half4 *>(vrow + (2 * s) * 16);
-      half4 v1 = *reinterpret_cast<const half4 *>(vrow + (2 * s + 1) * 16);
-      half8 vf;
+  for (int half = 0; half < 2; ++half) {
+    const f16 *vb = half ? ks : vlo;
+    if (half) __syncthreads();       // V^T(high) landed (vmcnt drained before the barrier)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        vf[r] = v0[r];
-        vf[4 + r] = v1[r];
+    for (int s = 0; s < 13; ++s) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int d = half * 64 + n * 16 + lq, sw = (d >> 2) & 3;
+        const f16 *vrow = vb + (n * 16 + lq) * AT_VROW + (g & 1) * 4;
+        half4 v0 = *reinterpret_cast<const half4 *>(vrow + (((4 * s + (g >> 1)) ^ sw) * 8));
+        half4 v1 = *reinterpret_cast<const half4 *>(vrow + (((4 * s + 2 + (g >> 1)) ^ sw) * 8));
+        half8 vf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          vf[r] = v0[r];
+          vf[4 + r] = v1[r];
+        }
+        oacc[half * 4 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfr[s], vf, oacc[half * 4 + n], 0, 0, 0);
       }
-      oacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, oacc[n], 0, 0, 0);
     }
   }
   // O accumulator: col = lq -> dim n*16+lq, row = 4g + r -> query (wave*16 + 4g + r).  inv belongs to
@@ -168,13 +168,11 @@ __global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__rest
 int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s) {
   FP_REQUIRE(T > 0 && T <= AT_MAXT, "attention: T=%d must be in [1,%d]", T, AT_MAXT);
   if (B == 0) return FP_OK;
-  const int ntile = (T + 15) / 16;
-  size_t lds_k = (size_t)ntile * 16 * AT_KLD * 2, lds_v = (size_t)AT_DH * AT_VLD * 2;
-  size_t lds = lds_k > lds_v ? lds_k : lds_v;
+  const size_t lds = AT_KBYTES + AT_VHALF;
   FP_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid(((T + AT_WAVES * 16 - 1) / (AT_WAVES * 16)) * 4 * B);
   ProfScope ps(ctx, s, "attention", 4.0 * B * 4 * (double)T * T * AT_DH);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(AT_THREADS), lds, s, qk, vt, T, out);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(AT_THREADS), lds, s, qk, vt, T, out, (const f16 *)ctx->zero_page);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
