@@ -7,172 +7,206 @@
 // src/Utils.py:848-855.
 #include "common.h"
 
-#define AT_WAVES 10
-#define AT_THREADS (AT_WAVES * 64)
 #define AT_DH 128
-#define AT_KLD 136   // halfs per K row in LDS (128 + 8 pad)  -> 272 B
-#define AT_TP 416    // padded token count of the transposed V image
-#define AT_VLD 424   // halfs per Vt row in LDS (416 + 8 pad)  -> 848 B
+#define AT_TP 416    // padded token count of the transposed V image [b][4][128][416]
 #define AT_MAXT 400
-
-// One workgroup = one (hypothesis, head, 160-query block); each of the 10 waves owns 16 queries.
-//   staging: K (400 x 128, 100 KB) and the low half of V^T (64 x 416, 52 KB) arrive by LDS-DMA
-//            (global_load_lds_dwordx4: every load of the tile in flight at once, no VGPRs); both images are
-//            lane-linear in LDS with the XOR swizzle applied on the SOURCE address (K: chunk ^ (key&15),
-//            V^T: chunk ^ ((d>>2)&3)) so the fragment reads are bank-conflict free.
-//   phase 1: S^T = K Q^T with v_mfma_f32_16x16x32_f16 (A = K tile from LDS, B = Q fragments held in
-//            registers) -> the lane owning query column q holds 4 keys per 16-key tile; the whole
-//            400-key row (100 fp32) stays in registers, softmax needs two xor-shuffles.
-//   phase 2: O = P V.  The S^T accumulator layout IS the A-operand layout of the next MFMA when two
-//            key tiles are paired per k-step with the k order (tile0: 4g+0..3, tile1: 4g+0..3); V is
-//            consumed from the transposed image so its B fragments are two 8-byte reads.  The high half
-//            of V^T is DMA'd over the (dead) K image while the low half is being multiplied.
-#define AT_VROW 416                    // halfs per V^T row (= AT_TP), 52 16-byte chunks
-#define AT_KBYTES (400 * 256)          // K image
-#define AT_VHALF (64 * AT_VROW * 2)    // one half of V^T
+#define FA_WAVES 7
+#define FA_NSTAGE 4
+#define FA_DMA_PER_WAVE 5   // ceil(32 DMA instructions per stage / 7 waves); surplus slots repeat an earlier one
+#define FA_THREADS (FA_WAVES * 64)
+#define FA_QB (FA_WAVES * 32)   // queries per workgroup
+#define FA_KB 64                // keys per pipeline stage
+#define FA_STAGE_HALFS (FA_KB * AT_DH * 2)   // K block [64][128] + V^T block [128][64]
 
 __device__ __forceinline__ void at_glds16(const f16 *g, f16 *l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(AT_THREADS) void attention_kernel(const f16 *__restrict__ qk, const f16 *__restrict__ vt, int T,
-                                                               f16 *__restrict__ out, const f16 *__restrict__ zero_page) {
+// Flash-style multi-head self-attention core (400 tokens, 4 heads x 128) on v_mfma_f32_32x32x16_f16.
+// One workgroup = one (hypothesis, head, 224-query block): 13 query tiles of 32 split 7 + 6 over two workgroups;
+// each of the 7 waves owns 32 queries and keeps Q^T (32 regs), the running max / sum and O^T (4 x 32x32
+// accumulators) in registers.  Keys stream through LDS in blocks of 64 (K block + V^T block = 32 KB) in a
+// 4-deep ring filled by LDS-DMA THREE blocks ahead: counted s_waitcnt vmcnt(N) + raw s_barrier keep the later
+// blocks in flight across the barrier (a __syncthreads() would drain them).  128 KB LDS, 1 workgroup per CU.
+//   S^T = K Q^T       : A = K rows from LDS (swizzled: chunk ^ (key&15), conflict-free b128), B = Q^T in registers;
+//                       the lane that owns query column q sees 16 of each 32 keys, its partner lane+32 the rest.
+//   online softmax     : per key block, max / sum finish with one xor-32 shuffle; exp((s-m)/sqrt(128)).
+//   O^T += V^T P^T     : the S^T accumulator registers 8s..8s+7 ARE the B operand of k-step s (key order
+//                       16s + {4h+0..3, 8+4h+0..3}); V^T comes from the transposed image as two 8-byte reads
+//                       in that same key order.  O^T keeps the query on the lane, so the rescale is lane-local.
+__global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__restrict__ qk, const f16 *__restrict__ vt, int T,
+                                                                  f16 *__restrict__ out, const f16 *__restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
-  f16 *ks = smem;                        // [400][128] swizzled; later V^T high half [64][416]
-  f16 *vlo = smem + AT_KBYTES / 2;       // V^T low half [64][416]
-  // 1-D grid, XCD-aware order: the query blocks of one (hypothesis, head) share K and V -> same XCD L2
-  const int nqb = (T + AT_WAVES * 16 - 1) / (AT_WAVES * 16);
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int nqb = (T + FA_QB - 1) / FA_QB;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);          // the query blocks of one (hypothesis, head) share an XCD L2
   const int qb = L % nqb, h = (L / nqb) & 3, b = L / (nqb * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lq = lane & 15, g = lane >> 4;
-  const int ntile = (T + 15) / 16;  // key tiles (25)
+  const int lr = lane & 31, lh = lane >> 5;
   const size_t rowbase = (size_t)b * T;
   const f16 *vsrc = vt + ((size_t)b * 4 + h) * AT_DH * AT_TP;
+  const int nkb = (T + FA_KB - 1) / FA_KB;
 
-  // ---- issue every K and V^T(low) DMA ----
-  for (int c0 = wave * 64; c0 < ntile * 256; c0 += AT_THREADS) {      // 16 chunks per key row
-    const int c = c0 + lane, key = c >> 4, chp = c & 15;
-    const f16 *src = key < T ? qk + (rowbase + key) * 1024 + 512 + h * AT_DH + ((chp ^ (key & 15)) * 8) : zero_page;
-    at_glds16(src, ks + (size_t)c0 * 8);
+  // Q^T fragments: loaded by inline asm and waited for by hand BEFORE the first LDS-DMA is issued.  With a
+  // compiler-visible load, hipcc sinks it below the DMAs and then drains vmcnt(0) at the first use of qf inside
+  // the key loop - every iteration - which serialises the whole DMA ring.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int q = qb * FA_QB + wave * 32 + lr;
+  u32x4 qv[8];
+  {
+    const f16 *qsrc = q < T ? qk + (rowbase + q) * 1024 + h * AT_DH + lh * 8 : zero_page;
+    const int step = q < T ? 16 : 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qv[s]) : "v"(qsrc + s * step) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]), "+v"(qv[4]), "+v"(qv[5]), "+v"(qv[6]), "+v"(qv[7])
+                 :
+                 : "memory");
   }
-  auto vstage = [&](int half, f16 *dst) {
-    for (int c0 = wave * 64; c0 < 64 * 52; c0 += AT_THREADS) {         // 52 chunks per row, 64 rows = 3328 = 52 x 64
-      const int c = c0 + lane, dl = c / 52, chp = c - dl * 52, d = half * 64 + dl;
-      at_glds16(vsrc + (size_t)d * AT_TP + ((chp ^ ((d >> 2) & 3)) * 8), dst + (size_t)c0 * 8);
+  half8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<half8 *>(&qv[s]);
+  auto stage = [&](int kb, int buf) {
+    f16 *kd = smem + buf * FA_STAGE_HALFS, *vd = kd + FA_KB * AT_DH;
+#pragma unroll
+    for (int u = 0; u < FA_DMA_PER_WAVE; ++u) {              // exactly FA_DMA_PER_WAVE per wave (vmcnt accounting)
+      int i = wave + u * FA_WAVES;
+      if (i >= 32) i -= 32;                                  // surplus slot: repeat an earlier instruction (same bytes)
+      if (i < 16) {                                          // K block: 64 keys x 16 chunks
+        const int c = i * 64 + lane, kl = c >> 4, chp = c & 15, key = kb * FA_KB + kl;
+        const f16 *src = key < T ? qk + (rowbase + key) * 1024 + 512 + h * AT_DH + ((chp ^ (kl & 15)) * 8) : zero_page;
+        at_glds16(src, kd + i * 512);
+      } else {                                               // V^T block: 128 dims x 8 chunks of 8 keys
+        const int c = (i - 16) * 64 + lane, d = c >> 3, chp = c & 7, k0 = kb * FA_KB + ((chp ^ ((d >> 1) & 7)) * 8);
+        const f16 *src = k0 < AT_TP ? vsrc + (size_t)d * AT_TP + k0 : zero_page;
+        at_glds16(src, vd + (i - 16) * 512);
+      }
     }
   };
-  vstage(0, vlo);
-  // ---- Q fragments: B operand, lane (q = lq, g) holds Q[q][32s + 8g .. +7] ----
-  const int q = qb * (AT_WAVES * 16) + wave * 16 + lq;
-  const bool qvalid = q < T;
-  half8 qf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (qvalid) v = *reinterpret_cast<const uint4 *>(qk + (rowbase + q) * 1024 + h * AT_DH + s * 32 + g * 8);
-    qf[s] = *reinterpret_cast<half8 *>(&v);
-  }
-  __syncthreads();   // hipcc drains vmcnt(0) before the barrier: K, V^T(low) and Q have landed
+  for (int p = 0; p < FA_NSTAGE - 1; ++p)
+    if (p < nkb) stage(p, p);
+  __builtin_amdgcn_sched_barrier(0);
 
-  // ---- phase 1: S^T tiles ----
-  floatx4 st[26];
+  floatx16 oacc[4];
 #pragma unroll
-  for (int t = 0; t < 26; ++t) st[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-  for (int t = 0; t < 25; ++t) {
-    if (t < ntile) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        half8 kf = *reinterpret_cast<const half8 *>(&ks[(t * 16 + lq) * 128 + (((s * 4 + g) ^ lq) * 8)]);
-        st[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], st[t], 0, 0, 0);
-      }
-    }
-  }
-  // ---- softmax over keys for query column lq (values spread over the 4 lane groups) ----
+    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
   const float scale = 0.08838834764831845f;  // 1/sqrt(128)
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int t = 0; t < 25; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int key = t * 16 + g * 4 + r;
-      if (key < T) mx = fmaxf(mx, st[t][r]);
-    }
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < 25; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int key = t * 16 + g * 4 + r;
-      float e = (key < T) ? __expf((st[t][r] - mx) * scale) : 0.f;
-      st[t][r] = e;
-      sum += e;
-    }
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.f / sum;
-  __syncthreads();  // everyone is done reading K
-  vstage(1, ks);    // V^T high half over the K image, in flight under phase 2a
 
-  // ---- phase 2: O = P V, 13 k-steps of 32 keys (two key tiles each), 8 n-tiles of 16 dims ----
-  floatx4 oacc[8];
+  for (int kb = 0; kb < nkb; ++kb) {
+    // block kb must have landed; the (up to two) younger blocks stay in flight across the barrier
+    const int younger = min(nkb - 1 - kb, FA_NSTAGE - 2);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (kb + FA_NSTAGE - 1 < nkb) stage(kb + FA_NSTAGE - 1, (kb + FA_NSTAGE - 1) % FA_NSTAGE);   // ring slot of block kb-1: free
+    const f16 *kd = smem + (kb % FA_NSTAGE) * FA_STAGE_HALFS, *vd = kd + FA_KB * AT_DH;
+    floatx16 sacc[2];
 #pragma unroll
-  for (int n = 0; n < 8; ++n) oacc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
-  half8 pfr[13];
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-  for (int s = 0; s < 13; ++s)
+      for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
+    // two independent accumulation chains (key tiles 0/1), fragments fetched four k-steps at a time so that
+    // eight LDS reads are in flight before the first MFMA of the group issues
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pfr[s][r] = (f16)st[2 * s][r];
-      pfr[s][4 + r] = (f16)st[2 * s + 1][r];
+    for (int sh = 0; sh < 2; ++sh) {
+      half8 kf[2][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          kf[kt][s] = *reinterpret_cast<const half8 *>(&kd[(kt * 32 + lr) * AT_DH + (((2 * (sh * 4 + s) + lh) ^ (lr & 15)) * 8)]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[sh * 4 + s], sacc[kt], 0, 0, 0);
     }
+    // ---- online softmax for query column lr (only the last key block can hold keys >= T) ----
+    const bool tail = (kb + 1) * FA_KB > T;
+    float bm = -1.0e30f;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const f16 *vb = half ? ks : vlo;
-    if (half) __syncthreads();       // V^T(high) landed (vmcnt drained before the barrier)
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int s = 0; s < 13; ++s) {
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int d = half * 64 + n * 16 + lq, sw = (d >> 2) & 3;
-        const f16 *vrow = vb + (n * 16 + lq) * AT_VROW + (g & 1) * 4;
-        half4 v0 = *reinterpret_cast<const half4 *>(vrow + (((4 * s + (g >> 1)) ^ sw) * 8));
-        half4 v1 = *reinterpret_cast<const half4 *>(vrow + (((4 * s + 2 + (g >> 1)) ^ sw) * 8));
-        half8 vf;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          vf[r] = v0[r];
-          vf[4 + r] = v1[r];
-        }
-        oacc[half * 4 + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pfr[s], vf, oacc[half * 4 + n], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * FA_KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (!tail || key < T) bm = fmaxf(bm, sacc[kt][r]);
       }
-    }
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    const float m_new = fmaxf(m_run, bm);
+    const float alpha = __expf((m_run - m_new) * scale);
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb * FA_KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float e = (!tail || key < T) ? __expf((sacc[kt][r] - m_new) * scale) : 0.f;
+        sacc[kt][r] = e;
+        ps += e;
+      }
+    ps += __shfl_xor(ps, 32);
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        half8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (f16)sacc[kt][8 * s2 + j];
+        const int chunk = kt * 4 + 2 * s2;
+        half4 v0[4], v1[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int d = dt * 32 + lr, sw = (d >> 1) & 7;
+          const f16 *vrow = vd + d * FA_KB + 4 * lh;
+          v0[dt] = *reinterpret_cast<const half4 *>(vrow + ((chunk ^ sw) * 8));
+          v1[dt] = *reinterpret_cast<const half4 *>(vrow + (((chunk + 1) ^ sw) * 8));
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          half8 vf;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            vf[j] = v0[dt][j];
+            vf[4 + j] = v1[dt][j];
+          }
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
+        }
+      }
   }
-  // O accumulator: col = lq -> dim n*16+lq, row = 4g + r -> query (wave*16 + 4g + r).  inv belongs to
-  // the query on column lq of phase 1, i.e. query index lq; fetch the right one per row.
+  // O^T accumulator: col = query lr, row = dim (r&3) + 8*(r>>2) + 4*lh of each 32-dim tile -> 8-byte stores
+  if (q < T) {
+    const float inv = 1.f / l_run;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qrow = 4 * g + r;
-    const float invq = __shfl(inv, qrow);  // lane qrow (g=0 copy) holds 1/sum of query qrow
-    const int qq = qb * (AT_WAVES * 16) + wave * 16 + qrow;
-    if (qq < T) {
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int n = 0; n < 8; ++n) out[(rowbase + qq) * 512 + h * AT_DH + n * 16 + lq] = (f16)(oacc[n][r] * invq);
-    }
+      for (int gq = 0; gq < 4; ++gq) {
+        half4 hv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv[j] = (f16)(oacc[dt][gq * 4 + j] * inv);
+        *reinterpret_cast<half4 *>(out + (rowbase + q) * 512 + h * AT_DH + dt * 32 + gq * 8 + lh * 4) = hv;
+      }
   }
 }
 
 int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s) {
   FP_REQUIRE(T > 0 && T <= AT_MAXT, "attention: T=%d must be in [1,%d]", T, AT_MAXT);
   if (B == 0) return FP_OK;
-  const size_t lds = AT_KBYTES + AT_VHALF;
+  const size_t lds = FA_NSTAGE * FA_STAGE_HALFS * sizeof(f16);
   FP_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  dim3 grid(((T + AT_WAVES * 16 - 1) / (AT_WAVES * 16)) * 4 * B);
+  dim3 grid(((T + FA_QB - 1) / FA_QB) * 4 * B);
   ProfScope ps(ctx, s, "attention", 4.0 * B * 4 * (double)T * T * AT_DH);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(AT_THREADS), lds, s, qk, vt, T, out, (const f16 *)ctx->zero_page);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(FA_THREADS), lds, s, qk, vt, T, out, (const f16 *)ctx->zero_page);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
