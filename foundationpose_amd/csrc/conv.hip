@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 // ------------------------------------------------------------------------------------------------
 // v2: 256 pixels x BM couts per workgroup, both operands staged by LDS-DMA (global_load_lds_dwordx4,
 // per-lane gather address, out-of-image taps read a zero page), XOR-swizzled 64-byte rows
-// (conflict-free ds_read_b128), 2 stages: the next K-step's DMA is in flight under the current
+// (conflict-free ds_read_b128), 3-deep ring: two K-steps of DMA are in flight under the current
 // step's 16 MFMAs per wave.  Used for the 1x1 (Linear) layers, the stride-2 3x3 and the 7x7 stem.
 // ------------------------------------------------------------------------------------------------
 #define C2_BN 256
@@ -283,11 +283,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int nk = p.Kpad / C2_BK;
+  // 3-deep LDS-DMA ring: K-steps kt+1 and kt+2 stay in flight across the barrier (counted vmcnt + raw s_barrier;
+  // a __syncthreads() would drain them).  Every wave issues exactly DMAW instructions per stage.
+  constexpr int DMAW = 4 + WQ;
+  static_assert(DMAW == 5 || DMAW == 6, "vmcnt immediates below assume 5 or 6 DMA instructions per wave per stage");
   stage(0, 0);
+  if (nk > 1) stage(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    __syncthreads();                       // stage kt landed (vmcnt drained before the barrier); buffer cur^1 is free
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const int cur = kt % 3;
+    if (kt + 1 < nk) {
+      if (DMAW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();          // stage kt landed for every wave; slot (kt+2)%3 was last read in step kt-1: free
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);
     const f16 *xs = smem + cur * (XH + WH), *ws = xs + XH;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -309,28 +321,49 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     f16 *stage = smem;
     constexpr int CPR = BM / 8;           // 16-byte chunks per staged row
     constexpr int NCH = C2_BN * CPR / 256;
+    constexpr int RB = NCH < 8 ? NCH : 8;
     if (p.res) {
-#pragma unroll 4
-      for (int i = 0; i < NCH; ++i) {
-        const int idx = tid + 256 * i, px = idx / CPR, c16 = idx % CPR;
-        const int m = m0 + px;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (m < p.M) v = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
-        *reinterpret_cast<uint4 *>(&stage[px * SLD + c16 * 8]) = v;
+#pragma unroll
+      for (int i0 = 0; i0 < NCH; i0 += RB) {
+        uint4 rv[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
+          const int m = min(m0 + px, p.M - 1);    // unconditional (clamped) load: a guarded one makes hipcc wait per element
+          rv[u] = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
+          *reinterpret_cast<uint4 *>(&stage[px * SLD + c16 * 8]) = rv[u];
+        }
       }
       __syncthreads();
     }
+    // bias / positional-embedding values fetched in batches before use (see conv_halo.hip)
+    float4 bvs[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) bvs[i][rg] = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int pxl = wn * 128 + j * 32 + lr;
-      int prow = 0;
-      if (p.post_add) prow = min(m0 + pxl, p.M - 1) % p.post_period;
+      float4 pvs[MT][4];
+      if (p.post_add) {
+        const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int col = wm * WM + i * 32 + rg * 8 + lh * 4;
-          const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + col);
+          const float4 bv = bvs[i][rg];
           float v[4] = {acc[i][j][rg * 4 + 0] + bv.x, acc[i][j][rg * 4 + 1] + bv.y, acc[i][j][rg * 4 + 2] + bv.z,
                         acc[i][j][rg * 4 + 3] + bv.w};
           f16 *sp = &stage[pxl * SLD + col];
@@ -344,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           if (p.post_add) {
-            const float4 pv = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + col);
+            const float4 pv = pvs[i][rg];
             v[0] += pv.x;
             v[1] += pv.y;
             v[2] += pv.z;
@@ -358,16 +391,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
       }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int i = 0; i < NCH; ++i) {
-      const int idx = tid + 256 * i, px = idx / CPR, c16 = idx % CPR;
-      const int m = m0 + px;
-      if (m < p.M) {
-        const bool hi = m >= p.split_m;
-        const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
-        const int coff = hi ? p.coff_hi : 0;
-        *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) =
-            *reinterpret_cast<const uint4 *>(&stage[px * SLD + c16 * 8]);
+#pragma unroll
+    for (int i0 = 0; i0 < NCH; i0 += RB) {
+      uint4 ov[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
+        ov[u] = *reinterpret_cast<const uint4 *>(&stage[px * SLD + c16 * 8]);
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
+        const int m = m0 + px;
+        if (m < p.M) {
+          const bool hi = m >= p.split_m;
+          const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+          const int coff = hi ? p.coff_hi : 0;
+          *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
+        }
       }
     }
     return;
@@ -437,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
 template <int BM, int KW, bool CIN8>
 static int launch_two(const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
   dim3 grid(((a.M + C2_BN - 1) / C2_BN) * (a.Cout / BM));
-  constexpr int main_b = 2 * (C2_BN * C2_BK + BM * C2_BK) * 2, epi_b = C2_BN * (BM + 8) * 2;
+  constexpr int main_b = 3 * (C2_BN * C2_BK + BM * C2_BK) * 2, epi_b = C2_BN * (BM + 8) * 2;
   constexpr int lds = main_b > epi_b ? main_b : epi_b;
   static bool attr_set = false;
   if (!attr_set) {

@@ -150,7 +150,20 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky, ++g) {
       const int buf = g & 1;
-      __syncthreads();        // weights(g) landed (vmcnt drained before the barrier), halo visible
+      // weights(g) must have landed and the halo stores must be visible.  The halo prefetch loads issued in
+      // group ky=0 are YOUNGER than the weights needed at ky=1, so a counted vmcnt leaves them in flight there
+      // (a __syncthreads() would drain them one group after issue).
+      if (ky == 1 && cc + 1 < nchunk) {
+        if constexpr (HLOADS == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+        else if constexpr (HLOADS == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else if constexpr (HLOADS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if constexpr (HLOADS == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
       {                       // prefetch the next group's weights into the other buffer
         int ncc = cc, nky = ky + 1;
         if (nky == 3) {
@@ -198,28 +211,51 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
   __syncthreads();
   f16 *stage = lds;   // [256 px][HL_SLD]
   if (p.res) {
-#pragma unroll 4
-    for (int i = 0; i < 4096 / NTH; ++i) {
-      const int idx = tid + NTH * i, px = idx >> 4, c16 = idx & 15;
-      const int m = m0 + px;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (m < p.M) v = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
-      *reinterpret_cast<uint4 *>(&stage[px * HL_SLD + c16 * 8]) = v;
+    // all loads of a batch are issued before the first ds_write (a load->store loop serialises their latencies)
+    constexpr int NRES = 4096 / NTH, RB = 8;
+#pragma unroll
+    for (int i0 = 0; i0 < NRES; i0 += RB) {
+      uint4 rv[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
+        const int m = min(m0 + px, p.M - 1);      // unconditional (clamped) load: a guarded one makes hipcc wait per element
+        rv[u] = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
+        *reinterpret_cast<uint4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
+      }
     }
     __syncthreads();
   }
+  // bias (and, where used, positional-embedding) values are fetched in batches BEFORE they are consumed: loaded
+  // one by one inside the loop hipcc waits vmcnt(0) after every load (32 serial L2 round trips per lane)
+  float4 bvs[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) bvs[i][rg] = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int pxl = wn * PXW + j * 32 + lr;
     const int m = m0 + pxl;
-    int prow = 0;
-    if (p.post_add) prow = min(m, p.M - 1) % p.post_period;
+    float4 pvs[2][4];
+    if (p.post_add) {
+      const int prow = min(m, p.M - 1) % p.post_period;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int col = wm * 64 + i * 32 + rg * 8 + lh * 4;   // channel within the 128-wide tile
-        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + col);
+        const float4 bv = bvs[i][rg];
         float v[4] = {acc[i][j][rg * 4 + 0] + bv.x, acc[i][j][rg * 4 + 1] + bv.y, acc[i][j][rg * 4 + 2] + bv.z,
                       acc[i][j][rg * 4 + 3] + bv.w};
         f16 *sp = &stage[pxl * HL_SLD + col];
@@ -233,7 +269,7 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.post_add) {
-          const float4 pv = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + col);
+          const float4 pv = pvs[i][rg];
           v[0] += pv.x;
           v[1] += pv.y;
           v[2] += pv.z;
@@ -247,16 +283,24 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
     }
   }
   __syncthreads();
-#pragma unroll 4
-  for (int i = 0; i < 4096 / NTH; ++i) {
-    const int idx = tid + NTH * i, px = idx >> 4, c16 = idx & 15;
-    const int m = m0 + px;
-    if (m < p.M) {
-      const bool hi = m >= p.split_m;
-      const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
-      const int coff = hi ? p.coff_hi : 0;
-      *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) =
-          *reinterpret_cast<const uint4 *>(&stage[px * HL_SLD + c16 * 8]);
+#pragma unroll
+  for (int i0 = 0; i0 < 4096 / NTH; i0 += 8) {
+    uint4 ov[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
+      ov[u] = *reinterpret_cast<const uint4 *>(&stage[px * HL_SLD + c16 * 8]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
+      const int m = m0 + px;
+      if (m < p.M) {
+        const bool hi = m >= p.split_m;
+        const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+        const int coff = hi ? p.coff_hi : 0;
+        *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
+      }
     }
   }
 }
