@@ -116,7 +116,7 @@ def cpu_baseline():
   os.environ['OMP_NUM_THREADS'] = str(cores)
   torch.set_num_threads(cores)
   sc = util.scene(0)
-  n_s = 16
+  n_s = 64
   orc = OracleFoundationPose(sc['mt'], sc['diameter'], sc['center'], sc['grid'][:n_s], S.make_refine_state_dict(0),
                              S.make_score_state_dict(1), refine_cfg=dict(REFINE_DEFAULT), score_cfg=dict(SCORE_DEFAULT))
   t0 = time.time()
@@ -188,7 +188,8 @@ def main():
       'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_halo_kernel (3x3 stride-1 convolutions: 93 % of the conv FLOPs)',
                    'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F16_TFLOPS,
                    'avg_launch_ms': conv['total_ms'] / max(conv['launches'], 1), 'launches': conv['launches'],
-                   'flops_per_launch': conv['flops'] / max(conv['launches'], 1), 'traffic': pmc_traffic()},
+                   'flops_per_launch': conv['flops'] / max(conv['launches'], 1),
+                   'traffic': (pmc_traffic() or {}).get('total'), 'traffic_detail': pmc_traffic()},
     }
     if not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()
