@@ -68,15 +68,15 @@ def step(est, objects, world, rank):
   the owning rank (object o is finalised by rank o % world)."""
   from foundationpose_amd.dist import all_gather_rows, pack_rows, shard_ranges, unpack_rows
   shard = math.ceil(N_HYP / world)
-  blocks = []
-  for ob in objects:
-    a, b = shard_ranges(N_HYP, world)[rank]
-    refined, _ = est.refiner.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=ob['rgb'], depth=ob['depth'], K=ob['K'],
-                                     ob_in_cams=ob['poses'][a:b], xyz_map=ob['xyz'], glctx=est.glctx, mesh_diameter=est.diameter,
-                                     iteration=ITER)
-    feats = est.scorer.extract_features(ob['rgb'], ob['depth'], ob['K'], refined, mesh=est.mesh, mesh_tensors=est.mesh_tensors,
-                                        glctx=est.glctx, mesh_diameter=est.diameter)
-    blocks.append((feats, refined))
+  a, b = shard_ranges(N_HYP, world)[rank]
+  # this rank's slice of EVERY object goes through the networks as one batch (render / crop stay per object)
+  refined = est.refiner.predict_multi([dict(rgb=ob['rgb'], xyz_map=ob['xyz'], K=ob['K'], mesh_tensors=est.mesh_tensors,
+                                            mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b]) for ob in objects], iteration=ITER)
+  n = b - a
+  feats = est.scorer.extract_features_multi([dict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], mesh_tensors=est.mesh_tensors,
+                                                  mesh_diameter=est.diameter, ob_in_cams=refined[o * n:(o + 1) * n])
+                                             for o, ob in enumerate(objects)])
+  blocks = [(feats[o * n:(o + 1) * n], refined[o * n:(o + 1) * n]) for o in range(len(objects))]
   results = {}
   if world > 1:
     rows = torch.cat([pack_rows(f, p, shard) for f, p in blocks], 0)          # (O*shard, 528)

@@ -26,6 +26,11 @@ class FpRefineCfg(Structure):
               ('trans_normalizer', c_float * 3), ('rot_normalizer', c_float)]
 
 
+class FpObjectBatch(Structure):
+  _fields_ = [('mesh', c_void_p), ('d_rgb', c_void_p), ('d_geom', c_void_p), ('H', c_int), ('W', c_int), ('K', c_void_p),
+              ('mesh_diameter', c_double), ('n', c_int)]
+
+
 class FoundationPoseAmdError(RuntimeError):
   pass
 
@@ -53,6 +58,8 @@ _PROTOS = {
   'fp_score_tail': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_pose_update': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p]),
   'fp_refine_predict': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, POINTER(FpRefineCfg), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_refine_predict_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, POINTER(FpRefineCfg), c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_score_predict_features_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, c_double, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_score_predict_features': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, c_double, c_int, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_conv2d_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
   'fp_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -194,6 +201,28 @@ def device_mesh(ctx, mesh_tensors):
     m = DeviceMesh(ctx, mesh_tensors)
     _mesh_cache[key] = m
   return m
+
+
+def object_batches(ctx, objects, geom_key):
+  """list of dicts (rgb, <geom_key>, K, mesh_tensors, mesh_diameter, ob_in_cams) -> (FpObjectBatch array, concatenated
+  poses (N,4,4) on the device, keep-alive list).  geom_key = 'xyz_map' (refiner) or 'depth' (scorer)."""
+  dev = torch.device('cuda', ctx.device_index)
+  arr = (FpObjectBatch * len(objects))()
+  keep, poses = [], []
+  for i, ob in enumerate(objects):
+    rgb = torch.as_tensor(ob['rgb'], device=dev, dtype=torch.float).contiguous()
+    geom = torch.as_tensor(ob[geom_key], device=dev, dtype=torch.float).contiguous()
+    Kd, _ = k_ptr(ob['K'])
+    dm = device_mesh(ctx, ob['mesh_tensors'])
+    p = torch.as_tensor(ob['ob_in_cams'], device=dev, dtype=torch.float).reshape(-1, 4, 4)
+    keep += [rgb, geom, Kd, dm]
+    poses.append(p)
+    arr[i].mesh, arr[i].d_rgb, arr[i].d_geom = dm.handle, rgb.data_ptr(), geom.data_ptr()
+    arr[i].H, arr[i].W = rgb.shape[0], rgb.shape[1]
+    arr[i].K = Kd.ctypes.data
+    arr[i].mesh_diameter = float(ob['mesh_diameter'])
+    arr[i].n = len(p)
+  return arr, torch.cat(poses, 0).contiguous().clone(), keep
 
 
 class DeviceNet:

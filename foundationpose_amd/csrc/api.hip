@@ -323,35 +323,106 @@ extern "C" int fp_pose_update(fp_ctx *ctx, const float *d_poseA, const float *d_
     return FP_ENOMEM;                                                                      \
   }
 
-extern "C" int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_xyz_map,
-                                 int H, int W, const double *K, double mesh_diameter, const fp_refine_cfg *cfg, float *d_poses, int N,
-                                 int iteration, float *d_trans, float *d_rot, void *stream) {
-  FP_REQUIRE(ctx && net && mesh && d_rgb && d_xyz_map && K && cfg && d_poses, "fp_refine_predict: null argument");
-  FP_REQUIRE(N >= 0 && iteration >= 0, "fp_refine_predict: bad N/iteration");
+static int check_objs(const fp_object_batch *objs, int n_obj, int *total) {
+  FP_REQUIRE(objs && n_obj >= 1, "multi: need at least one object");
+  int N = 0;
+  for (int o = 0; o < n_obj; ++o) {
+    FP_REQUIRE(objs[o].mesh && objs[o].d_rgb && objs[o].d_geom && objs[o].K, "multi: object %d has a null field", o);
+    FP_REQUIRE(objs[o].n >= 0 && objs[o].H > 1 && objs[o].W > 1 && objs[o].mesh_diameter > 0, "multi: object %d has a bad shape", o);
+    N += objs[o].n;
+  }
+  *total = N;
+  return FP_OK;
+}
+
+extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
+                                       float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream) {
+  FP_REQUIRE(ctx && net && cfg && d_poses, "fp_refine_predict_multi: null argument");
+  FP_REQUIRE(iteration >= 0, "fp_refine_predict_multi: bad iteration");
+  int N = 0;
+  FP_TRY(check_objs(objs, n_obj, &N));
   if (N == 0 || iteration == 0) return FP_OK;
   hipStream_t s = (hipStream_t)stream;
   const int rot_dim = fp_net_rot_dim(net);
   FP_TRY(fp_arena_ensure(ctx, fp_arena_bytes_for(N)));
   const size_t mark = ctx->arena.off;
+  const size_t img = (size_t)160 * 160 * 8;
   auto body = [&]() -> int {
     TAKE(tf, float, (size_t)N * 9);
     TAKE(bbox, float, (size_t)N * 4);
     TAKE(trans, float, (size_t)N * 3);
     TAKE(rot, float, (size_t)N * 6);
     TAKE(pose_tmp, float, (size_t)N * 16);
-    TAKE(net_in, f16, (size_t)2 * N * 160 * 160 * 8);
+    TAKE(net_in, f16, (size_t)2 * N * img);
     float *tr = d_trans ? d_trans : trans, *ro = d_rot ? d_rot : rot;
-    const float trans_scale = cfg->normalize_xyz ? (float)(mesh_diameter / 2) : 1.f;
     for (int it = 0; it < iteration; ++it) {
-      FP_TRY(launch_crop_window_tf(d_poses, N, K, cfg->crop_ratio, mesh_diameter, 160, 160, tf, bbox, s));
-      FP_TRY(fp_render_net(ctx, mesh, d_poses, N, K, H, W, bbox, 160, 160, mesh_diameter, cfg->normalize_xyz, 0.001f, net_in, s));
-      FP_TRY(fp_crop_observed(ctx, d_rgb, d_xyz_map, H, W, K, tf, d_poses, N, 160, 160, 0, mesh_diameter, cfg->normalize_xyz, 1,
-                              net_in + (size_t)N * 160 * 160 * 8, s));
-      FP_TRY(fp_refine_forward(ctx, net, net_in, N, tr, ro, s));
-      FP_TRY(launch_pose_update(d_poses, tr, ro, N, rot_dim, cfg->trans_rep_tanh, cfg->trans_normalizer[0], cfg->trans_normalizer[1],
-                                cfg->trans_normalizer[2], cfg->rot_normalizer, trans_scale, pose_tmp, s));
+      int off = 0;
+      for (int o = 0; o < n_obj; ++o) {       // per-object: crop window, render (side A), observed crop (side B)
+        const fp_object_batch &ob = objs[o];
+        if (ob.n == 0) continue;
+        float *p = d_poses + (size_t)off * 16;
+        FP_TRY(launch_crop_window_tf(p, ob.n, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, s));
+        FP_TRY(fp_render_net(ctx, ob.mesh, p, ob.n, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
+                             cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, s));
+        FP_TRY(fp_crop_observed(ctx, ob.d_rgb, ob.d_geom, ob.H, ob.W, ob.K, tf + (size_t)off * 9, p, ob.n, 160, 160, 0, ob.mesh_diameter,
+                                cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, s));
+        off += ob.n;
+      }
+      FP_TRY(fp_refine_forward(ctx, net, net_in, N, tr, ro, s));     // ONE network pass for every object
+      off = 0;
+      for (int o = 0; o < n_obj; ++o) {
+        const fp_object_batch &ob = objs[o];
+        if (ob.n == 0) continue;
+        const float trans_scale = cfg->normalize_xyz ? (float)(ob.mesh_diameter / 2) : 1.f;
+        FP_TRY(launch_pose_update(d_poses + (size_t)off * 16, tr + (size_t)off * 3, ro + (size_t)off * rot_dim, ob.n, rot_dim,
+                                  cfg->trans_rep_tanh, cfg->trans_normalizer[0], cfg->trans_normalizer[1], cfg->trans_normalizer[2],
+                                  cfg->rot_normalizer, trans_scale, pose_tmp + (size_t)off * 16, s));
+        off += ob.n;
+      }
       FP_CHECK_HIP(hipMemcpyAsync(d_poses, pose_tmp, (size_t)N * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
+    return FP_OK;
+  };
+  int rc = body();
+  ctx->arena.off = mark;
+  return rc;
+}
+
+extern "C" int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_xyz_map,
+                                 int H, int W, const double *K, double mesh_diameter, const fp_refine_cfg *cfg, float *d_poses, int N,
+                                 int iteration, float *d_trans, float *d_rot, void *stream) {
+  FP_REQUIRE(N >= 0, "fp_refine_predict: bad N");
+  fp_object_batch ob = {mesh, d_rgb, d_xyz_map, H, W, K, mesh_diameter, N};
+  return fp_refine_predict_multi(ctx, net, &ob, 1, cfg, d_poses, iteration, d_trans, d_rot, stream);
+}
+
+extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, double crop_ratio,
+                                               int normalize_xyz, const float *d_poses, float *d_feats, void *stream) {
+  FP_REQUIRE(ctx && net && d_poses && d_feats, "fp_score_predict_features_multi: null argument");
+  int N = 0;
+  FP_TRY(check_objs(objs, n_obj, &N));
+  if (N == 0) return FP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  FP_TRY(fp_arena_ensure(ctx, fp_arena_bytes_for(N)));
+  const size_t mark = ctx->arena.off;
+  const size_t img = (size_t)160 * 160 * 8;
+  auto body = [&]() -> int {
+    TAKE(tf, float, (size_t)N * 9);
+    TAKE(bbox, float, (size_t)N * 4);
+    TAKE(net_in, f16, (size_t)2 * N * img);
+    int off = 0;
+    for (int o = 0; o < n_obj; ++o) {
+      const fp_object_batch &ob = objs[o];
+      if (ob.n == 0) continue;
+      const float *p = d_poses + (size_t)off * 16;
+      FP_TRY(launch_crop_window_tf(p, ob.n, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, s));
+      FP_TRY(fp_render_net(ctx, ob.mesh, p, ob.n, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
+                           net_in + (size_t)off * img, s));
+      FP_TRY(fp_crop_observed(ctx, ob.d_rgb, ob.d_geom, ob.H, ob.W, ob.K, tf + (size_t)off * 9, p, ob.n, 160, 160, 1, ob.mesh_diameter,
+                              normalize_xyz, 1, net_in + ((size_t)N + off) * img, s));
+      off += ob.n;
+    }
+    FP_TRY(fp_score_features(ctx, net, net_in, N, d_feats, s));
     return FP_OK;
   };
   int rc = body();
@@ -362,26 +433,9 @@ extern "C" int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *
 extern "C" int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_depth,
                                          int H, int W, const double *K, double mesh_diameter, double crop_ratio, int normalize_xyz,
                                          const float *d_poses, int N, float *d_feats, void *stream) {
-  FP_REQUIRE(ctx && net && mesh && d_rgb && d_depth && K && d_poses && d_feats, "fp_score_predict_features: null argument");
   FP_REQUIRE(N >= 0, "fp_score_predict_features: N<0");
-  if (N == 0) return FP_OK;
-  hipStream_t s = (hipStream_t)stream;
-  FP_TRY(fp_arena_ensure(ctx, fp_arena_bytes_for(N)));
-  const size_t mark = ctx->arena.off;
-  auto body = [&]() -> int {
-    TAKE(tf, float, (size_t)N * 9);
-    TAKE(bbox, float, (size_t)N * 4);
-    TAKE(net_in, f16, (size_t)2 * N * 160 * 160 * 8);
-    FP_TRY(launch_crop_window_tf(d_poses, N, K, crop_ratio, mesh_diameter, 160, 160, tf, bbox, s));
-    FP_TRY(fp_render_net(ctx, mesh, d_poses, N, K, H, W, bbox, 160, 160, mesh_diameter, normalize_xyz, 0.1f, net_in, s));
-    FP_TRY(fp_crop_observed(ctx, d_rgb, d_depth, H, W, K, tf, d_poses, N, 160, 160, 1, mesh_diameter, normalize_xyz, 1,
-                            net_in + (size_t)N * 160 * 160 * 8, s));
-    FP_TRY(fp_score_features(ctx, net, net_in, N, d_feats, s));
-    return FP_OK;
-  };
-  int rc = body();
-  ctx->arena.off = mark;
-  return rc;
+  fp_object_batch ob = {mesh, d_rgb, d_depth, H, W, K, mesh_diameter, N};
+  return fp_score_predict_features_multi(ctx, net, &ob, 1, crop_ratio, normalize_xyz, d_poses, d_feats, stream);
 }
 
 // ---- building blocks ---------------------------------------------------------------------------------

@@ -59,6 +59,34 @@ class PoseRefinePredictor:
     self.last_trans_update = None
     self.last_rot_update = None
 
+  def _c_cfg(self):
+    """fp_refine_cfg for the C-ABI from the reference's config keys (predict_pose_refine.py:195-231)."""
+    c = FpRefineCfg()
+    c.crop_ratio = float(self.cfg['crop_ratio'])
+    c.normalize_xyz = 1 if self.cfg['normalize_xyz'] else 0
+    c.trans_rep_tanh = 1 if (self.cfg['trans_rep'] == 'tracknet' and not self.cfg['normalize_xyz']) else 0
+    tn = self.cfg['trans_normalizer']
+    tn = [float(tn)] * 3 if isinstance(tn, (float, int)) else [float(x) for x in tn]
+    for i in range(3):
+      c.trans_normalizer[i] = tn[i]
+    c.rot_normalizer = float(self.cfg['rot_normalizer'])
+    return c
+
+  @torch.inference_mode()
+  def predict_multi(self, objects, iteration=5):
+    """Several objects in one pass (BASELINE configs[3]; a rank's slices in the sharded job): `objects` is a list of
+    dicts(rgb, xyz_map, K, mesh_tensors, mesh_diameter, ob_in_cams).  Render / crop run per object, RefineNet once on
+    the concatenated hypotheses.  Returns the refined poses concatenated in object order."""
+    arr, poses, keep = _lib.object_batches(self.ctx, objects, 'xyz_map')
+    c = self._c_cfg()
+    N = len(poses)
+    trans = torch.empty((N, 3), device=poses.device, dtype=torch.float)
+    rot = torch.empty((N, self.model.rot_dim), device=poses.device, dtype=torch.float)
+    check(lib().fp_refine_predict_multi(self.ctx.handle, self.model.handle, arr, len(objects), byref(c), ptr(poses), int(iteration),
+                                        ptr(trans), ptr(rot), stream_ptr(poses.device)))
+    self.last_trans_update, self.last_rot_update = trans, rot
+    return poses
+
   @torch.inference_mode()
   def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None, mesh_tensors=None, glctx=None,
               mesh_diameter=None, iteration=5):
@@ -83,16 +111,7 @@ class PoseRefinePredictor:
     xyz_t = torch.as_tensor(xyz_map, device=dev, dtype=torch.float).contiguous()
     H, W = rgb_t.shape[:2]
     assert xyz_t.shape[:2] == (H, W)
-    c = FpRefineCfg()
-    c.crop_ratio = float(self.cfg['crop_ratio'])
-    c.normalize_xyz = 1 if self.cfg['normalize_xyz'] else 0
-    tanh_branch = (self.cfg['trans_rep'] == 'tracknet') and not self.cfg['normalize_xyz']
-    c.trans_rep_tanh = 1 if tanh_branch else 0
-    tn = self.cfg['trans_normalizer']
-    tn = [float(tn)] * 3 if isinstance(tn, (float, int)) else [float(x) for x in tn]
-    for i in range(3):
-      c.trans_normalizer[i] = tn[i]
-    c.rot_normalizer = float(self.cfg['rot_normalizer'])
+    c = self._c_cfg()
     trans = torch.empty((N, 3), device=dev, dtype=torch.float)
     rot = torch.empty((N, self.model.rot_dim), device=dev, dtype=torch.float)
     Kd, Kp = k_ptr(K)

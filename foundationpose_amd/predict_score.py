@@ -62,6 +62,16 @@ class ScorePredictor:
     return feats
 
   @torch.inference_mode()
+  def extract_features_multi(self, objects):
+    """`objects`: list of dicts(rgb, depth, K, mesh_tensors, mesh_diameter, ob_in_cams) -> (sum n, 512) features,
+    one ScoreNet pass for all objects (see PoseRefinePredictor.predict_multi)."""
+    arr, poses, keep = _lib.object_batches(self.ctx, objects, 'depth')
+    feats = torch.empty((len(poses), 512), dtype=torch.float, device=poses.device)
+    check(lib().fp_score_predict_features_multi(self.ctx.handle, self.model.handle, arr, len(objects), float(self.cfg['crop_ratio']),
+                                                1 if self.cfg['normalize_xyz'] else 0, ptr(poses), ptr(feats), stream_ptr(poses.device)))
+    return feats
+
+  @torch.inference_mode()
   def score_tail(self, feats, L=None):
     """att_cross + linear over groups of L hypotheses (score_network.py:82-88): (groups*L,512) -> (groups,L)."""
     feats = feats.contiguous()

@@ -133,6 +133,24 @@ int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const
                       int H, int W, const double *K, double mesh_diameter, const fp_refine_cfg *cfg, float *d_poses, int N,
                       int iteration, float *d_trans, float *d_rot, void *stream);
 
+/* Several objects (frames / meshes) in ONE pass: the render + crop stages run per object, the networks run once on the
+ * concatenated hypotheses (they are object-agnostic).  This is BASELINE configs[3] (4 concurrent objects x 252) and what
+ * a rank of the sharded multi-GPU job executes (its slice of every object).  d_poses / d_trans / d_rot / d_feats are the
+ * concatenation over objects in order; objs[i].n hypotheses belong to object i. */
+typedef struct {
+  const fp_mesh *mesh;
+  const float *d_rgb;      /* H*W*3 float [0,255] */
+  const float *d_geom;     /* refine: xyz_map H*W*3; score: depth H*W */
+  int H, W;
+  const double *K;         /* host, 3x3 row-major */
+  double mesh_diameter;
+  int n;                   /* hypotheses of this object */
+} fp_object_batch;
+int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
+                            float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream);
+int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, double crop_ratio,
+                                    int normalize_xyz, const float *d_poses, float *d_feats, void *stream);
+
 /* a18-a20: ScorePredictor.predict up to per-hypothesis features (shardable), then the tail. */
 int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_depth,
                               int H, int W, const double *K, double mesh_diameter, double crop_ratio, int normalize_xyz,

@@ -136,3 +136,32 @@ def test_renderer_determinism_and_pose_locality(env):
   c = render(poses)
   same = (a == c).flatten(1).all(1)
   assert not bool(same[17]) and bool(same[torch.arange(N, device='cuda') != 17].all())
+
+
+def test_multi_object_pass_equals_per_object_passes(env):
+  """configs[3]-style batching (fp_refine_predict_multi / fp_score_predict_features_multi): two objects (different
+  frames, 100 + 152 hypotheses) through ONE network pass per iteration == each object on its own, bit for bit."""
+  from oracle import geometry as G
+  sc, refiner, scorer = env['sc'], env['refiner'], env['scorer']
+  sc2 = util.scene(1)
+  depth2 = G.bilateral_filter_depth(G.erode_depth(sc2['depth']))
+  objs = [dict(rgb=sc['rgb'], depth=env['depth'], xyz_map=env['xyz'], K=sc['K'], mesh_tensors=env['mt'], mesh_diameter=sc['diameter'],
+               ob_in_cams=env['poses'][:100]),
+          dict(rgb=sc2['rgb'], depth=depth2, xyz_map=G.depth2xyzmap(depth2, sc2['K']), K=sc2['K'], mesh_tensors=env['mt'],
+               mesh_diameter=sc['diameter'], ob_in_cams=torch.from_numpy(util.hypotheses(sc2, 152)).cuda())]
+  refined = refiner.predict_multi(objs, iteration=2)
+  assert refined.shape == (252, 4, 4)
+  parts = []
+  for ob in objs:
+    p, _ = refiner.predict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], ob_in_cams=ob['ob_in_cams'], xyz_map=ob['xyz_map'],
+                           mesh_tensors=ob['mesh_tensors'], mesh_diameter=ob['mesh_diameter'], iteration=2)
+    parts.append(p)
+  assert torch.equal(refined, torch.cat(parts, 0))
+  feats = scorer.extract_features_multi([dict(ob, ob_in_cams=p) for ob, p in zip(objs, parts)])
+  fparts = [scorer.extract_features(ob['rgb'], ob['depth'], ob['K'], p, mesh_tensors=ob['mesh_tensors'], mesh_diameter=ob['mesh_diameter'])
+            for ob, p in zip(objs, parts)]
+  assert torch.equal(feats, torch.cat(fparts, 0))
+  # an object with zero hypotheses on this rank is legal (252 hypotheses over more ranks than shards)
+  empty = dict(objs[0], ob_in_cams=env['poses'][:0])
+  r2 = refiner.predict_multi([empty, objs[1]], iteration=1)
+  assert r2.shape == (152, 4, 4)
