@@ -19,52 +19,56 @@
 // to fp16, LDS transpose, 16-byte row-contiguous NHWC stores.
 #include "common.h"
 
-#define HL_TM 256
+#define HL_TM 256   // pixels per workgroup of the main tiles (tail tiles: 64, see conv3x3_halo_kernel)
 #define HL_BM 128
 #define HL_CK 32
 #define HL_SLD 136  // halfs per staged output row (128 + 8 pad) -> 272 B
 #define HL_PS 40    // halfs per halo pixel (32 channels + 8 pad = 80 B): conflict-free ds_read_b128 AND every tap
                     // shift / k-step is a compile-time immediate offset from ONE base register per pixel tile
 
-template <int W>
+template <int W, int TM = HL_TM>
 struct HaloCfg {
-  static constexpr int MAXSLOT = (W - 1 + HL_TM - 1) / W + 1 + 2;  // input rows a 256-pixel run can touch (+1 above, +1 below)
+  static constexpr int MAXSLOT = (W - 1 + TM - 1) / W + 1 + 2;     // input rows a TM-pixel run can touch (+1 above, +1 below)
   static constexpr int HALO_CHUNKS = MAXSLOT * W * 4;              // 16-byte chunks (4 per pixel at 32 channels)
   static constexpr int HALO_HALFS = (MAXSLOT * W + 2) * HL_PS + 8; // pixel p lives at index p+1; + one zero chunk
   static constexpr int ZERO_OFF = (MAXSLOT * W + 2) * HL_PS;       // half offset of the zero chunk
   static constexpr int halo_loads(int nth) { return (HALO_CHUNKS + nth - 1) / nth; }
   static constexpr int WBUF_HALFS = 3 * HL_BM * HL_CK;             // one kernel row of taps
   static constexpr int LDS_HALFS_MAIN = HALO_HALFS + 2 * WBUF_HALFS;
-  static constexpr int LDS_HALFS_EPI = HL_TM * HL_SLD;
+  static constexpr int LDS_HALFS_EPI = TM * HL_SLD;
   static constexpr int LDS_BYTES = 2 * (LDS_HALFS_MAIN > LDS_HALFS_EPI ? LDS_HALFS_MAIN : LDS_HALFS_EPI);
 };
 
-__device__ __forceinline__ void glds16(const f16 *g, f16 *l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+// LDS-DMA issued from inline asm.  Through __builtin_amdgcn_global_load_lds the compiler marks a "flat access that may
+// touch LDS" as pending until the next full drain, and while that mark is up EVERY wait it inserts for an LDS fragment read
+// is s_waitcnt lgkmcnt(0) (and every barrier drains vmcnt(0)) - no LDS read can stay in flight under the MFMAs.  Hidden in
+// asm, the DMA is outside its bookkeeping: fragment reads get counted lgkmcnt(n); the DMA's completion is waited for by
+// the explicit s_waitcnt vmcnt(n) in front of the barriers below.  m0 = wave-uniform LDS byte address, lane i lands at +16 i.
+__device__ __forceinline__ void glds16(const f16 *sbase, unsigned voff_bytes, f16 *l) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)l);
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(sbase), "s"(la) : "memory");
 }
 
-// NWN = wave columns: 2 -> 4 waves, each 64 co x 128 px (2x4 tiles, <=256 VGPRs, 2 waves/SIMD at 2 WG/CU);
-//                     4 -> 8 waves, each 64 co x 64 px (2x2 tiles, <=128 VGPRs, 4 waves/SIMD at 2 WG/CU)
-template <int W, int NWN>
-__global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p) {
-  using C = HaloCfg<W>;
+// One workgroup tile: 4 waves as 2 (cout halves) x 2 (pixel halves); each wave 64 co x 32*NT px (2 x NT accumulator tiles).
+// NT = 4 -> 256-pixel tile (the main tiles), NT = 1 -> 64-pixel tile (tail tiles).  The accumulation order of every output
+// element (chunk, ky, kx, k-step) does not depend on NT, so the tile shape never changes a result bit.
+template <int W, int NT>
+__device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const int c0, f16 *lds) {
+  constexpr int TM = 64 * NT;
+  using C = HaloCfg<W, TM>;
   constexpr int H = W;
-  constexpr int NTH = 128 * NWN;        // threads
-  constexpr int NT = 8 / NWN;           // 32-pixel tiles per wave
+  constexpr int NWN = 2;
+  constexpr int NTH = 256;              // threads
   constexpr int PXW = 32 * NT;          // pixels per wave
   constexpr int HLOADS = C::halo_loads(NTH);
   constexpr int WQ = 24 / (2 * NWN);    // weight DMA instructions per wave per group
-  extern __shared__ __attribute__((aligned(16))) f16 lds[];
   f16 *halo = lds;
   f16 *wbuf = lds + C::HALO_HALFS;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 31, lh = lane >> 5;
-  const int n_ct = p.Cout / HL_BM;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);          // 1-D grid; consecutive L = cout tiles of one pixel tile, then the next pixel tile
-  const int m0 = (L / n_ct) * HL_TM, c0 = (L % n_ct) * HL_BM;
   const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by slot 0
-  const int mlast = min(m0 + HL_TM - 1, p.M - 1);
+  const int mlast = min(m0 + TM - 1, p.M - 1);
   const int NS = mlast / W + 1 - GR0 + 1;           // slots in use
   const int total_rows = p.Nimg * H;
   const int nchunk = p.Cin / HL_CK;
@@ -98,17 +102,25 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
   }
 
   // ---- halo staging: global -> registers (prefetch) -> LDS ----
+  // load i of thread tid fetches 16-byte chunk (tid + 256 i): pixel tid/4 + 64 i, channel group tid%4 -> one 32-bit lane
+  // offset for all loads and chunks, the rest of the address is wave-uniform (scalar); row validity is a 7-bit lane mask
   uint4 hreg[HLOADS];
+  unsigned hoff = (unsigned)((tid >> 2) * p.Cin + (tid & 3) * 8);
+  unsigned hmask = 0;
+#pragma unroll
+  for (int i = 0; i < HLOADS; ++i) {
+    const int slot = ((tid >> 2) + 64 * i) / W, gr = GR0 + slot;
+    if (slot < NS && gr >= 0 && gr < total_rows) hmask |= 1u << i;
+  }
+  const f16 *hbase = p.in + (long long)GR0 * W * p.Cin;
   auto halo_load = [&](int cc) {
+    unsigned off = hoff;
+    asm volatile("" : "+v"(off));     // keep the offset 32-bit inside the loop (hoisted, hipcc widens it into 7 register pairs)
 #pragma unroll
     for (int i = 0; i < HLOADS; ++i) {
-      const int idx = tid + NTH * i;
-      const int pix = idx >> 2, ch = idx & 3;        // pix = slot*W + px
-      const int slot = pix / W;
-      const int gr = GR0 + slot;
+      const f16 *cb = hbase + cc * HL_CK + i * 64 * p.Cin;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (slot < NS && gr >= 0 && gr < total_rows)
-        v = *reinterpret_cast<const uint4 *>(p.in + ((long long)GR0 * W + pix) * p.Cin + cc * HL_CK + ch * 8);
+      if ((hmask >> i) & 1u) v = *reinterpret_cast<const uint4 *>(cb + off);
       hreg[i] = v;
     }
   };
@@ -121,14 +133,14 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
     }
   };
   // ---- weights: one kernel row (3 taps) per group, LDS-DMA, lane-linear image with the swizzle on the SOURCE ----
+  // instruction q of wave w covers tap kx = q/2, couts ((q&1)*4 + w)*16 + lane/4, 16-byte channel group lane%4 (swizzled):
+  // the lane part of the source address is the same for every q, group and chunk
+  const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
   auto wstage = [&](int cc, int ky, int buf) {
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
-      const int L = (q * 2 * NWN + wave) * 64 + lane;  // linear 16-byte position in the 3x128x4 image
-      const int kx = L >> 9, rem = L & 511, co = rem >> 2, chp = rem & 3;
-      const int ch = chp ^ ((co >> 2) & 3);
-      const f16 *src = p.w + (size_t)(c0 + co) * p.Kpad + (ky * 3 + kx) * p.Cin + cc * HL_CK + ch * 8;
-      glds16(src, wbuf + buf * C::WBUF_HALFS + (q * 2 * NWN + wave) * 512);
+      const f16 *sb = p.w + (size_t)(c0 + (q & 1) * 64) * p.Kpad + (ky * 3 + (q >> 1)) * p.Cin + cc * HL_CK;
+      glds16(sb, woff, wbuf + buf * C::WBUF_HALFS + (q * 2 * NWN + wave) * 512);
     }
   };
 
@@ -154,11 +166,11 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
       // group ky=0 are YOUNGER than the weights needed at ky=1, so a counted vmcnt leaves them in flight there
       // (a __syncthreads() would drain them one group after issue).
       if (ky == 1 && cc + 1 < nchunk) {
+        static_assert(HLOADS == 7 || HLOADS == 5 || HLOADS == 4 || HLOADS == 3, "add the vmcnt immediate for this tile");
         if constexpr (HLOADS == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
         else if constexpr (HLOADS == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
         else if constexpr (HLOADS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if constexpr (HLOADS == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
@@ -183,25 +195,39 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
         vm[j] = vmask[j];
         asm volatile("" : "+v"(vm[j]));
       }
+      // software pipeline over the 6 (kx, k-step) steps of this kernel row, in an order that needs only one spare
+      // weight-fragment pair: MFMAs go pixel-tile-major, so a pixel fragment is dead after two MFMAs and its register is
+      // reloaded for the NEXT step right away - every fragment is requested >= 6 MFMAs (192 cycles) before its first use.
+      // sched_barrier(0) pins that order; the waits the compiler inserts are then counted lgkmcnt(n), not lgkmcnt(0).
+      half8 af[2][2], bf[NT];
+      auto load_a = [&](int st, int set) {
+        const int kx = st >> 1, ks = st & 1;
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
+        for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const half8 *>(&wb[wa[ks] + i * (32 * 32) + kx * (HL_BM * HL_CK)]);
+      };
+      auto load_b = [&](int st, int j) {
+        const int kx = st >> 1, ks = st & 1;
+        const int imm = (ky * W + kx) * HL_PS + ks * 16;
+        const bool ok = (vm[j] >> (ky * 3 + kx)) & 1u;
+        const int base = ok ? pb[j] : (C::ZERO_OFF - imm);
+        bf[j] = *reinterpret_cast<const half8 *>(&halo[base + imm]);
+      };
+      load_a(0, 0);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          half8 af[2], bf[NT];
+      for (int j = 0; j < NT; ++j) load_b(0, j);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const half8 *>(&wb[wa[ks] + i * (32 * 32) + kx * (HL_BM * HL_CK)]);
+      for (int st = 0; st < 6; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < 6) load_a(st + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            constexpr int dummy = 0;
-            const int imm = (ky * W + kx) * HL_PS + ks * 16;
-            const bool ok = (vm[j] >> (ky * 3 + kx)) & 1u;
-            const int base = ok ? pb[j] : (C::ZERO_OFF - imm);
-            bf[j] = *reinterpret_cast<const half8 *>(&halo[base + imm + dummy]);
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][0], bf[j], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][1], bf[j], acc[1][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < 6) load_b(st + 1, j);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -212,7 +238,7 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
   f16 *stage = lds;   // [256 px][HL_SLD]
   if (p.res) {
     // all loads of a batch are issued before the first ds_write (a load->store loop serialises their latencies)
-    constexpr int NRES = 4096 / NTH, RB = 8;
+    constexpr int NRES = TM * 16 / NTH, RB = NRES < 8 ? NRES : 8;
 #pragma unroll
     for (int i0 = 0; i0 < NRES; i0 += RB) {
       uint4 rv[RB];
@@ -283,16 +309,17 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
     }
   }
   __syncthreads();
+  constexpr int NOUT = TM * 16 / NTH, OB = NOUT < 8 ? NOUT : 8;
 #pragma unroll
-  for (int i0 = 0; i0 < 4096 / NTH; i0 += 8) {
-    uint4 ov[8];
+  for (int i0 = 0; i0 < NOUT; i0 += OB) {
+    uint4 ov[OB];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < OB; ++u) {
       const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
       ov[u] = *reinterpret_cast<const uint4 *>(&stage[px * HL_SLD + c16 * 8]);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < OB; ++u) {
       const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
       const int m = m0 + px;
       if (m < p.M) {
@@ -305,32 +332,69 @@ __global__ __launch_bounds__(128 * NWN, NWN) void conv3x3_halo_kernel(ConvArgs p
   }
 }
 
+// Grid = n_main workgroups of 256 px x 128 co, then n_tail4 workgroups of 64 px x 128 co covering the LAST main-size tiles
+// cut in four.  With two workgroups resident per CU a launch has 512 slots; 3150 equal tiles (N=252: every layer of the
+// network) would leave 84 % of the chip idle for the whole seventh round - cutting only the remainder into quarters lets
+// that round end after a quarter of the time.  (Cutting every tile would cost the big tile's operand reuse.)
+template <int W>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p, int n_main) {
+  extern __shared__ __attribute__((aligned(16))) f16 lds[];
+  const int n_ct = p.Cout / HL_BM;
+  if ((int)blockIdx.x < n_main) {
+    const int L = xcd_remap(blockIdx.x, n_main);   // consecutive L = cout tiles of one pixel tile, then the next pixel tile
+    halo_tile<W, 4>(p, (L / n_ct) * HL_TM, (L % n_ct) * HL_BM, lds);
+  } else {
+    const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
+    const int L = n_main + (t >> 2);
+    const int m0 = (L / n_ct) * HL_TM + (t & 3) * 64;
+    if (m0 >= p.M) return;
+    halo_tile<W, 1>(p, m0, (L % n_ct) * HL_BM, lds);
+  }
+}
+
 bool conv_halo_supported(const ConvArgs &a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H == a.W && (a.W == 40 || a.W == 20) && a.Cin % HL_CK == 0 &&
          a.Cout % HL_BM == 0 && a.out_mode == 0 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0;
 }
 
-template <int W, int NWN>
+int g_halo_tail = 1;   // FP_HALO_TAIL=0 disables the tail split (A/B timing only; results are identical)
+
+// main/tail split: whole rounds of `slots` main tiles stay; the remainder is cut in four when that shortens the last round
+// (a quarter tile costs ~0.35 of a main tile: less operand reuse), i.e. when the remainder fills < ~70 % of a round.
+static void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
+  const int rem = n_tiles % slots;
+  *n_main = n_tiles;
+  *n_tail4 = 0;
+  if (!g_halo_tail || rem == 0 || n_tiles < slots) return;
+  const double cost_whole = 1.0, cost_quarter = 0.35 * ((4 * rem + slots - 1) / slots);
+  if (cost_quarter < cost_whole) {
+    *n_main = n_tiles - rem;
+    *n_tail4 = 4 * rem;
+  }
+}
+
+template <int W>
 static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
   using C = HaloCfg<W>;
   static bool attr_set = false;
+  static int slots = 512;
   if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    int dev = 0, cus = 256;
+    FP_CHECK_HIP(hipGetDevice(&dev));
+    FP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    slots = 2 * cus;
     attr_set = true;
   }
-  dim3 grid(((a.M + HL_TM - 1) / HL_TM) * (a.Cout / HL_BM));
-  hipLaunchKernelGGL((conv3x3_halo_kernel<W, NWN>), grid, dim3(128 * NWN), C::LDS_BYTES, s, a);
+  const int n_tiles = ((a.M + HL_TM - 1) / HL_TM) * (a.Cout / HL_BM);
+  int n_main, n_tail4;
+  halo_split(n_tiles, slots, &n_main, &n_tail4);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<W>), dim3(n_main + n_tail4), dim3(256), C::LDS_BYTES, s, a, n_main);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
 
-int g_halo_nwn = 2;   // tuning knob (FP_HALO_NWN env, read once in api.hip)
-
 int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
-  if (g_halo_nwn == 2) {
-    if (a.W == 40) return launch_halo_w<40, 2>(a, s);
-    return launch_halo_w<20, 2>(a, s);
-  }
-  if (a.W == 40) return launch_halo_w<40, 4>(a, s);
-  return launch_halo_w<20, 4>(a, s);
+  if (a.W == 40) return launch_halo_w<40>(a, s);
+  return launch_halo_w<20>(a, s);
 }
