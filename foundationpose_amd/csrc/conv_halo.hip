@@ -19,12 +19,19 @@
 // to fp16, LDS transpose, 16-byte row-contiguous NHWC stores.
 #include "common.h"
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte register value (plain vector loads / stores in IR)
+
 #define HL_TM 256   // pixels per workgroup of the main tiles (tail tiles: 64, see conv3x3_halo_kernel)
 #define HL_BM 128
 #define HL_CK 32
 #define HL_SLD 136  // halfs per staged output row (128 + 8 pad) -> 272 B
 #define HL_PS 40    // halfs per halo pixel (32 channels + 8 pad = 80 B): conflict-free ds_read_b128 AND every tap
                     // shift / k-step is a compile-time immediate offset from ONE base register per pixel tile
+
+template <int V>
+struct IC {
+  static constexpr int value = V;
+};
 
 template <int W, int TM = HL_TM>
 struct HaloCfg {
@@ -102,43 +109,42 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
   }
 
   // ---- halo staging: global -> registers (prefetch) -> LDS ----
-  // load i of thread tid fetches 16-byte chunk (tid + 256 i): pixel tid/4 + 64 i, channel group tid%4 -> one 32-bit lane
-  // offset for all loads and chunks, the rest of the address is wave-uniform (scalar); row validity is a 7-bit lane mask
-  uint4 hreg[HLOADS];
-  unsigned hoff = (unsigned)((tid >> 2) * p.Cin + (tid & 3) * 8);
-  unsigned hmask = 0;
-#pragma unroll
-  for (int i = 0; i < HLOADS; ++i) {
-    const int slot = ((tid >> 2) + 64 * i) / W, gr = GR0 + slot;
-    if (slot < NS && gr >= 0 && gr < total_rows) hmask |= 1u << i;
-  }
-  const f16 *hbase = p.in + (long long)GR0 * W * p.Cin;
-  auto halo_load = [&](int cc) {
-    unsigned off = hoff;
-    asm volatile("" : "+v"(off));     // keep the offset 32-bit inside the loop (hoisted, hipcc widens it into 7 register pairs)
-#pragma unroll
-    for (int i = 0; i < HLOADS; ++i) {
-      const f16 *cb = hbase + cc * HL_CK + i * 64 * p.Cin;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if ((hmask >> i) & 1u) v = *reinterpret_cast<const uint4 *>(cb + off);
-      hreg[i] = v;
-    }
+  // Load i of thread tid fetches 16-byte chunk (tid + 256 i): band pixel tid/4 + 64 i, channel group tid%4.  Rows outside
+  // the tensor (above the first / below the last image, or past the slots in use) are CLAMPED to a valid pixel instead of
+  // skipped: what lands there is never read (those taps select the zero chunk through vmask), and every wave then
+  // issues exactly HLOADS loads - the counted vmcnt at ky=1 depends on that.  Offsets are 32-bit from the tensor base.
+  u32x4 hreg[HLOADS];
+  const int hpix0 = GR0 * W + (tid >> 2), hpix_max = total_rows * W - 1;
+  auto halo_load = [&](int cc, auto i0c, auto i1c) __attribute__((always_inline)) {     // loads I0 .. I1-1 of chunk cc (compile-time range: hreg stays in registers)
+    constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value < HLOADS ? decltype(i1c)::value : HLOADS;
+    int px0 = hpix0;
+    asm volatile("" : "+v"(px0));     // recompute the 32-bit offsets per chunk (hoisted, hipcc keeps 7 register pairs alive)
+    auto one = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i >= I0 && i < I1) {
+        const int px = min(max(px0 + 64 * i, 0), hpix_max);
+        hreg[i] = *reinterpret_cast<const u32x4 *>(p.in + (unsigned)(px * p.Cin + cc * HL_CK + (tid & 3) * 8));
+      }
+    };
+    one(IC<0>{}), one(IC<1>{}), one(IC<2>{}), one(IC<3>{}), one(IC<4>{}), one(IC<5>{}), one(IC<6>{});
+    static_assert(HLOADS <= 7, "extend the list");
   };
-  auto halo_store = [&]() {
+  auto halo_store = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < HLOADS; ++i) {
       const int idx = tid + NTH * i;
       const int pix = idx >> 2, ch = idx & 3;
-      if (idx < C::HALO_CHUNKS) *reinterpret_cast<uint4 *>(&halo[(pix + 1) * HL_PS + ch * 8]) = hreg[i];
+      if (idx < C::HALO_CHUNKS) *reinterpret_cast<u32x4 *>(&halo[(pix + 1) * HL_PS + ch * 8]) = hreg[i];
     }
   };
   // ---- weights: one kernel row (3 taps) per group, LDS-DMA, lane-linear image with the swizzle on the SOURCE ----
   // instruction q of wave w covers tap kx = q/2, couts ((q&1)*4 + w)*16 + lane/4, 16-byte channel group lane%4 (swizzled):
   // the lane part of the source address is the same for every q, group and chunk
   const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
-  auto wstage = [&](int cc, int ky, int buf) {
+  auto wstage = [&](int cc, int ky, int buf, auto q0c, auto q1c) __attribute__((always_inline)) {     // DMA instructions Q0 .. Q1-1 of group (cc, ky)
+    constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
 #pragma unroll
-    for (int q = 0; q < WQ; ++q) {
+    for (int q = Q0; q < Q1; ++q) {
       const f16 *sb = p.w + (size_t)(c0 + (q & 1) * 64) * p.Kpad + (ky * 3 + (q >> 1)) * p.Cin + cc * HL_CK;
       glds16(sb, woff, wbuf + buf * C::WBUF_HALFS + (q * 2 * NWN + wave) * 512);
     }
@@ -152,9 +158,9 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (tid < 1) *reinterpret_cast<uint4 *>(&halo[C::ZERO_OFF]) = make_uint4(0, 0, 0, 0);
-  halo_load(0);
-  wstage(0, 0, 0);
+  if (tid < 1) *reinterpret_cast<u32x4 *>(&halo[C::ZERO_OFF]) = u32x4{0, 0, 0, 0};
+  halo_load(0, IC<0>{}, IC<HLOADS>{});
+  wstage(0, 0, 0, IC<0>{}, IC<WQ>{});
   int g = 0;
   for (int cc = 0; cc < nchunk; ++cc) {
     __syncthreads();          // every wave is done reading the previous chunk's halo
@@ -176,17 +182,16 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
       }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      {                       // prefetch the next group's weights into the other buffer
-        int ncc = cc, nky = ky + 1;
-        if (nky == 3) {
-          nky = 0;
-          ncc = cc + 1;
-        }
-        if (ncc < nchunk) wstage(ncc, nky, buf ^ 1);
+      // The next group's weights (into the other buffer) and, in group ky=0, the next chunk's halo (into registers) are
+      // requested from INSIDE the MFMA steps below - two DMAs after the first MFMA pair of steps 0..2, the halo loads in
+      // steps 3..5 - so their issue cycles (~60 per DMA) sit under running MFMAs instead of in front of the group.
+      // Program order stays "DMAs, then halo loads": the counted vmcnt at ky=1 relies on it.
+      int ncc = cc, nky = ky + 1;
+      if (nky == 3) {
+        nky = 0;
+        ncc = cc + 1;
       }
-      // next chunk's halo -> registers, issued AFTER this group's barrier so that the barrier's vmcnt(0)
-      // drain (hipcc drains every VMEM op before s_barrier while an LDS-DMA is pending) does not expose it
-      if (ky == 0 && cc + 1 < nchunk) halo_load(cc + 1);
+      const bool more_w = ncc < nchunk, more_h = (ky == 0) && (cc + 1 < nchunk);
       const f16 *wb = wbuf + buf * C::WBUF_HALFS;
       // keep the per-tap border selects INSIDE the loop: hoisted, their 72 results would not fit the register file
       unsigned vm[NT];
@@ -200,12 +205,12 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
       // reloaded for the NEXT step right away - every fragment is requested >= 6 MFMAs (192 cycles) before its first use.
       // sched_barrier(0) pins that order; the waits the compiler inserts are then counted lgkmcnt(n), not lgkmcnt(0).
       half8 af[2][2], bf[NT];
-      auto load_a = [&](int st, int set) {
+      auto load_a = [&](int st, int set) __attribute__((always_inline)) {
         const int kx = st >> 1, ks = st & 1;
 #pragma unroll
         for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const half8 *>(&wb[wa[ks] + i * (32 * 32) + kx * (HL_BM * HL_CK)]);
       };
-      auto load_b = [&](int st, int j) {
+      auto load_b = [&](int st, int j) __attribute__((always_inline)) {
         const int kx = st >> 1, ks = st & 1;
         const int imm = (ky * W + kx) * HL_PS + ks * 16;
         const bool ok = (vm[j] >> (ky * 3 + kx)) & 1u;
@@ -216,9 +221,8 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
 #pragma unroll
       for (int j = 0; j < NT; ++j) load_b(0, j);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int st = 0; st < 6; ++st) {
-        const int cur = st & 1;
+      auto step = [&](auto stc) __attribute__((always_inline)) {
+        constexpr int st = decltype(stc)::value, cur = st & 1;
         if (st + 1 < 6) load_a(st + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -227,9 +231,23 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
           acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][1], bf[j], acc[1][j], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if (st + 1 < 6) load_b(st + 1, j);
+          if (j == 0) {
+            if constexpr (st < 3) {
+              if (more_w) wstage(ncc, nky, buf ^ 1, IC<2 * st>{}, IC<2 * st + 2>{});
+            } else {
+              constexpr int HP = (HLOADS + 2) / 3;
+              if (more_h) halo_load(cc + 1, IC<(st - 3) * HP>{}, IC<(st - 3) * HP + HP>{});
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
+      };
+      step(IC<0>{});
+      step(IC<1>{});
+      step(IC<2>{});
+      step(IC<3>{});
+      step(IC<4>{});
+      step(IC<5>{});
     }
   }
 
@@ -241,17 +259,17 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
     constexpr int NRES = TM * 16 / NTH, RB = NRES < 8 ? NRES : 8;
 #pragma unroll
     for (int i0 = 0; i0 < NRES; i0 += RB) {
-      uint4 rv[RB];
+      u32x4 rv[RB];
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
         const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
         const int m = min(m0 + px, p.M - 1);      // unconditional (clamped) load: a guarded one makes hipcc wait per element
-        rv[u] = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
+        rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
       }
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
         const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
-        *reinterpret_cast<uint4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
+        *reinterpret_cast<u32x4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
       }
     }
     __syncthreads();
@@ -312,11 +330,11 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
   constexpr int NOUT = TM * 16 / NTH, OB = NOUT < 8 ? NOUT : 8;
 #pragma unroll
   for (int i0 = 0; i0 < NOUT; i0 += OB) {
-    uint4 ov[OB];
+    u32x4 ov[OB];
 #pragma unroll
     for (int u = 0; u < OB; ++u) {
       const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
-      ov[u] = *reinterpret_cast<const uint4 *>(&stage[px * HL_SLD + c16 * 8]);
+      ov[u] = *reinterpret_cast<const u32x4 *>(&stage[px * HL_SLD + c16 * 8]);
     }
 #pragma unroll
     for (int u = 0; u < OB; ++u) {
@@ -326,7 +344,7 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
         const bool hi = m >= p.split_m;
         const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
         const int coff = hi ? p.coff_hi : 0;
-        *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
+        *reinterpret_cast<u32x4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
       }
     }
   }
