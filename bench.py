@@ -191,6 +191,13 @@ def main():
                    'flops_per_launch': conv['flops'] / max(conv['launches'], 1),
                    'traffic': (pmc_traffic() or {}).get('total'), 'traffic_detail': pmc_traffic()},
     }
+    classes = {}
+    for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'render'):
+      r = ctx.prof_read(c)
+      if r['launches']:
+        classes[c] = {'ms_per_step': r['total_ms'] / args.steps, 'launches_per_step': r['launches'] / args.steps,
+                      'tflops': (r['flops'] / (r['total_ms'] * 1e-3) / 1e12) if r['flops'] else None}
+    out['kernel_classes'] = classes       # HIP-event time per kernel class (same events as the roofline figure)
     if not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

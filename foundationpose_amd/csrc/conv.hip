@@ -11,182 +11,16 @@
 // channels per register quad => 8-byte channel-contiguous NHWC stores, and the "V transposed"
 // store used by the attention kernel ([b][head][d][token]) is lane-contiguous.
 //
-// Tile: 128 pixels x BM couts (BM = 128 | 64) per 256-thread workgroup, 2x2 waves, each wave
-// (BM/2) x 64 via v_mfma_f32_32x32x16_f16; K-step 32, register-staged global->LDS with the next
-// step's loads issued before the current step's MFMAs, LDS rows padded to 80 B (conflict-free
-// ds_read_b128 fragment reads), double-buffered, one barrier per K-step.
+// Tile: 256 pixels x BM couts (BM = 128 | 64) per 256-thread workgroup, 2x2 waves, each wave (BM/2) x 128 via
+// v_mfma_f32_32x32x16_f16; both operands staged by LDS-DMA through a 3-deep ring (below).  The 3x3 stride-1 layers
+// have their own kernel (conv_halo.hip).
 #include "common.h"
 #include <cstdlib>
 
-#define CV_BN 128
 #define CV_BK 32
-#define CV_LD 40  // halfs per LDS row (32 + 8 pad)
-
-template <int BM, int KW, bool CIN8>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
-  __shared__ __attribute__((aligned(16))) f16 sW[2][BM * CV_LD];
-  __shared__ __attribute__((aligned(16))) f16 sX[2][CV_BN * CV_LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  constexpr int WM = BM / 2;
-  constexpr int MT = WM / 32;
-  constexpr int NT = 2;
-  constexpr int WROWS = BM / 64;  // weight rows per thread (2 or 1)
-  const int m0 = blockIdx.x * CV_BN;
-  const int c0 = blockIdx.y * BM;
-  const int HoWo = p.Ho * p.Wo;
-  const int ntaps = p.KH * p.KW;
-
-  // ---- per-thread gather rows (fixed over the K loop) ----
-  const int cc = tid & 3;      // 16-byte chunk within the 32-wide K step
-  const int rbase = tid >> 2;  // 0..63
-  long long xbase[2];
-  int iy0[2], ix0[2];
-  bool mval[2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    int m = m0 + rbase + 64 * r;
-    mval[r] = m < p.M;
-    int mm = mval[r] ? m : 0;
-    int n = mm / HoWo, rem = mm - n * HoWo;
-    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-    iy0[r] = oy * p.stride - p.pad;
-    ix0[r] = ox * p.stride - p.pad;
-    xbase[r] = (long long)n * p.H * p.W * p.Cin;
-  }
-  const f16 *wrow[WROWS];
-#pragma unroll
-  for (int r = 0; r < WROWS; ++r) wrow[r] = p.w + (size_t)(c0 + rbase + 64 * r) * p.Kpad + cc * 8;
-
-  uint4 xreg[2], wreg[WROWS];
-  auto gload = [&](int kt) {
-    const int k = kt * CV_BK + cc * 8;
-    int tap, ci;
-    if (CIN8) {
-      tap = k >> 3;
-      ci = 0;
-    } else {
-      tap = (kt * CV_BK) / p.Cin;
-      ci = k - tap * p.Cin;
-    }
-    const int ky = tap / KW, kx = tap - ky * KW;
-    const bool tval = tap < ntaps;
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      int iy = iy0[r] + ky, ix = ix0[r] + kx;
-      bool ok = mval[r] && tval && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4 *>(p.in + xbase[r] + ((long long)iy * p.W + ix) * p.Cin + ci);
-      xreg[r] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < WROWS; ++r) wreg[r] = *reinterpret_cast<const uint4 *>(wrow[r] + (size_t)kt * CV_BK);
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r) *reinterpret_cast<uint4 *>(&sX[buf][(rbase + 64 * r) * CV_LD + cc * 8]) = xreg[r];
-#pragma unroll
-    for (int r = 0; r < WROWS; ++r) *reinterpret_cast<uint4 *>(&sW[buf][(rbase + 64 * r) * CV_LD + cc * 8]) = wreg[r];
-  };
-
-  floatx16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int nk = p.Kpad / CV_BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  const int lr = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 af[MT], bf[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        af[i] = *reinterpret_cast<const half8 *>(&sW[cur][(wm * WM + i * 32 + lr) * CV_LD + ks * 16 + lh * 8]);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        bf[j] = *reinterpret_cast<const half8 *>(&sX[cur][(wn * 64 + j * 32 + lr) * CV_LD + ks * 16 + lh * 8]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) lstore(cur ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane owns pixel (lane&31), channels 8*rg + 4*(lane>>5) + [0,4) of each 32x32 tile ----
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int m = m0 + wn * 64 + j * 32 + lr;
-    if (m >= p.M) continue;
-    const bool hi = m >= p.split_m;
-    const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
-    const int coff = hi ? p.coff_hi : 0;
-    int prow = 0;
-    if (p.post_add) prow = m % p.post_period;
-    int tb = 0, tt = 0;
-    if (p.out_mode == 2) {
-      tb = m / p.tokens;
-      tt = m - tb * p.tokens;
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int co = c0 + wm * WM + i * 32 + rg * 8 + lh * 4;
-        float v[4];
-        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co);
-        v[0] = acc[i][j][rg * 4 + 0] + bv.x;
-        v[1] = acc[i][j][rg * 4 + 1] + bv.y;
-        v[2] = acc[i][j][rg * 4 + 2] + bv.z;
-        v[3] = acc[i][j][rg * 4 + 3] + bv.w;
-        if (p.res) {
-          half4 rv = *reinterpret_cast<const half4 *>(p.res + (size_t)m * p.Cout + co);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (p.post_add) {
-          const float4 pv = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + co);
-          v[0] += pv.x;
-          v[1] += pv.y;
-          v[2] += pv.z;
-          v[3] += pv.w;
-        }
-        if (p.out_mode == 0) {
-          half4 hv;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
-          *reinterpret_cast<half4 *>((f16 *)p.out + orow * p.out_ld + coff + co) = hv;
-        } else if (p.out_mode == 1) {
-          *reinterpret_cast<float4 *>((float *)p.out + orow * p.out_ld + coff + co) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = co + e, h = c >> 7, d = c & 127;
-            ((f16 *)p.out)[(((size_t)tb * 4 + h) * 128 + d) * 416 + tt] = (f16)v[e];
-          }
-        }
-      }
-    }
-  }
-}
-
 
 // ------------------------------------------------------------------------------------------------
-// v2: 256 pixels x BM couts per workgroup, both operands staged by LDS-DMA (global_load_lds_dwordx4,
+// 256 pixels x BM couts per workgroup, both operands staged by LDS-DMA (global_load_lds_dwordx4,
 // per-lane gather address, out-of-image taps read a zero page), XOR-swizzled 64-byte rows
 // (conflict-free ds_read_b128), 3-deep ring: two K-steps of DMA are in flight under the current
 // step's 16 MFMAs per wave.  Used for the 1x1 (Linear) layers, the stride-2 3x3 and the 7x7 stem.
@@ -194,8 +28,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #define C2_BN 256
 #define C2_BK 32
 
+// LDS-DMA from inline asm (see conv_halo.hip: through the builtin hipcc turns every later LDS-read wait into lgkmcnt(0) and
+// every barrier into a full vmcnt(0) drain).  Completion is waited for by the explicit s_waitcnt vmcnt(n) before the barriers.
 __device__ __forceinline__ void glds16c(const f16 *g, f16 *l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)l);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");
 }
 
 template <int BM, int KW, bool CIN8>
@@ -237,10 +74,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     const int co = (q * 4 + wave) * 16 + (lane >> 2);
     wsrc[q] = p.w + (size_t)(c0 + co) * p.Kpad + ((chp ^ ((co >> 2) & 3)) * 8);
   }
-  auto stage = [&](int kt, int buf) {
+  // DMA instruction d of a stage: d = 0..3 the activation gather (pixel group d), d = 4.. the weights
+  auto stage_one = [&](int kt, int buf, int d) __attribute__((always_inline)) {
     f16 *xs = smem + buf * (XH + WH), *ws = xs + XH;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    if (d < 4) {
+      const int q = d;
       const int k = kt * C2_BK + xch[q] * 8;
       int tap, ci;
       if (CIN8) {
@@ -255,9 +93,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
       const bool ok = tap < ntaps && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       const f16 *src = ok ? p.in + xbase[q] + ((long long)iy * p.W + ix) * p.Cin + ci : zero_page;
       glds16c(src, xs + (q * 4 + wave) * 512);
+    } else {
+      const int q = d - 4;
+      glds16c(wsrc[q] + (size_t)kt * C2_BK, ws + (q * 4 + wave) * 512);
     }
+  };
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < WQ; ++q) glds16c(wsrc[q] + (size_t)kt * C2_BK, ws + (q * 4 + wave) * 512);
+    for (int d = 0; d < 4 + WQ; ++d) stage_one(kt, buf, d);
   };
 
   // ---- fragment bases (swizzled rows: chunk ^ ((row>>2)&3); rows +32 keep the same swizzle) ----
@@ -301,17 +144,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);
     const f16 *xs = smem + cur * (XH + WH), *ws = xs + XH;
+    // two k-steps per stage, software-pipelined like the halo kernel: pixel-tile-major MFMA order, the pixel fragment of
+    // step 1 is requested as soon as step 0's MFMAs on that register have been issued (counted lgkmcnt waits).  (Issuing
+    // the DMAs of stage kt+2 from between the MFMAs, as the halo kernel does, was measured 2-4 % slower here: these layers
+    // are bound by the L2 -> LDS fill, and the fill wants its requests as early as possible.)
+    half8 af[2][MT], bf[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[0][i] = *reinterpret_cast<const half8 *>(&ws[wa[0] + i * 32 * 32]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const half8 *>(&xs[xa[j][0]]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[1][i] = *reinterpret_cast<const half8 *>(&ws[wa[1] + i * 32 * 32]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      half8 af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const half8 *>(&ws[wa[ks] + i * 32 * 32]);
+      for (int j = 0; j < NT; ++j) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const half8 *>(&xs[xa[j][ks]]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][i], bf[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) bf[j] = *reinterpret_cast<const half8 *>(&xs[xa[j][1]]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 
@@ -415,6 +269,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
   }
 
   // ---- epilogue, other output modes (fp32 NHWC, transposed V): direct stores ----
+  float4 bvd[MT][4];     // bias fetched once, before use (a load inside the loops is waited for with vmcnt(0) each time)
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) bvd[i][rg] = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int m = m0 + wn * 128 + j * 32 + lr;
@@ -435,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
       for (int rg = 0; rg < 4; ++rg) {
         const int co = c0 + wm * WM + i * 32 + rg * 8 + lh * 4;
         float v[4];
-        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co);
+        const float4 bv = bvd[i][rg];
         v[0] = acc[i][j][rg * 4 + 0] + bv.x;
         v[1] = acc[i][j][rg * 4 + 1] + bv.y;
         v[2] = acc[i][j][rg * 4 + 2] + bv.z;
@@ -487,14 +346,6 @@ static int launch_two(const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
   }
   FP_REQUIRE(a.out_mode != 0 || (a.out_ld % 8 == 0 && a.coff_hi % 8 == 0), "conv: out_ld/coff must be multiples of 8 for fp16 output");
   hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8>), grid, dim3(256), lds, s, a, zero_page);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-template <int BM, int KW, bool CIN8>
-static int launch_one(const ConvArgs &a, hipStream_t s) {
-  dim3 grid((a.M + CV_BN - 1) / CV_BN, a.Cout / BM);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, KW, CIN8>), grid, dim3(256), 0, s, a);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
