@@ -18,22 +18,39 @@
 // Epilogue: bias (+ residual staged through LDS) + ReLU (+ positional embedding) in fp32, one rounding
 // to fp16, LDS transpose, 16-byte row-contiguous NHWC stores.
 #include "common.h"
+#include <cstdlib>
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte register value (plain vector loads / stores in IR)
 
-#define HL_TM 256   // pixels per workgroup of the main tiles (tail tiles: 64, see conv3x3_halo_kernel)
+
 #define HL_BM 128
 #define HL_CK 32
 #define HL_SLD 136  // halfs per staged output row (128 + 8 pad) -> 272 B
 #define HL_PS 40    // halfs per halo pixel (32 channels + 8 pad = 80 B): conflict-free ds_read_b128 AND every tap
                     // shift / k-step is a compile-time immediate offset from ONE base register per pixel tile
 
+#ifdef HALO_STAMP
+// diagnostic build only (make STAMP=1): per-wave cycle sums of [wait + barrier] and [group body], see scripts/halo_stamps.py
+__device__ unsigned long long g_halo_stamps[4096 * 8 * 8];
+extern "C" int fp_dbg_halo_stamps(unsigned long long *host, int clear) {
+  if (host) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps));
+  if (clear) {
+    static unsigned long long z[4096 * 8 * 8];
+    hipMemcpyToSymbol(HIP_SYMBOL(g_halo_stamps), z, sizeof(z));
+  }
+  return 0;
+}
+#define STAMP(x) x
+#else
+#define STAMP(x)
+#endif
+
 template <int V>
 struct IC {
   static constexpr int value = V;
 };
 
-template <int W, int TM = HL_TM>
+template <int W, int TM>
 struct HaloCfg {
   static constexpr int MAXSLOT = (W - 1 + TM - 1) / W + 1 + 2;     // input rows a TM-pixel run can touch (+1 above, +1 below)
   static constexpr int HALO_CHUNKS = MAXSLOT * W * 4;              // 16-byte chunks (4 per pixel at 32 channels)
@@ -56,27 +73,26 @@ __device__ __forceinline__ void glds16(const f16 *sbase, unsigned voff_bytes, f1
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(sbase), "s"(la) : "memory");
 }
 
-// One workgroup tile: 4 waves as 2 (cout halves) x 2 (pixel halves); each wave 64 co x 32*NT px (2 x NT accumulator tiles).
-// NT = 4 -> 256-pixel tile (the main tiles), NT = 1 -> 64-pixel tile (tail tiles).  The accumulation order of every output
-// element (chunk, ky, kx, k-step) does not depend on NT, so the tile shape never changes a result bit.
-template <int W, int NT>
-__device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const int c0, f16 *lds) {
-  constexpr int TM = 64 * NT;
+// One workgroup tile: 2 NPW waves as 2 (cout halves) x NPW (pixel columns); each wave 64 co x 32*NT px (2 x NT accumulator
+// tiles), i.e. 128 couts x 32*NT*NPW pixels per workgroup.  NT = 4 -> main tiles, NT = 1 -> tail tiles.  The accumulation
+// order of every output element (chunk, ky, kx, k-step) does not depend on NT / NPW: the tile shape never changes a bit.
+template <int W, int NT, int NPW, bool RES, bool POST>
+__device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const int c0, f16 *lds, const int dbg) {
+  constexpr int TM = 32 * NT * NPW;
   using C = HaloCfg<W, TM>;
   constexpr int H = W;
-  constexpr int NWN = 2;
-  constexpr int NTH = 256;              // threads
+  constexpr int NWN = NPW;
+  constexpr int NTH = 128 * NPW;        // threads
   constexpr int PXW = 32 * NT;          // pixels per wave
   constexpr int HLOADS = C::halo_loads(NTH);
   constexpr int WQ = 24 / (2 * NWN);    // weight DMA instructions per wave per group
+  STAMP(const unsigned long long t_entry = __builtin_amdgcn_s_memtime(); const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();)
   f16 *halo = lds;
   f16 *wbuf = lds + C::HALO_HALFS;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NWN, wn = wave % NWN;
   const int lr = lane & 31, lh = lane >> 5;
   const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by slot 0
-  const int mlast = min(m0 + TM - 1, p.M - 1);
-  const int NS = mlast / W + 1 - GR0 + 1;           // slots in use
   const int total_rows = p.Nimg * H;
   const int nchunk = p.Cin / HL_CK;
 
@@ -109,7 +125,7 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
   }
 
   // ---- halo staging: global -> registers (prefetch) -> LDS ----
-  // Load i of thread tid fetches 16-byte chunk (tid + 256 i): band pixel tid/4 + 64 i, channel group tid%4.  Rows outside
+  // Load i of thread tid fetches 16-byte chunk (tid + NTH i): band pixel tid/4 + NTH/4 i, channel group tid%4.  Rows outside
   // the tensor (above the first / below the last image, or past the slots in use) are CLAMPED to a valid pixel instead of
   // skipped: what lands there is never read (those taps select the zero chunk through vmask), and every wave then
   // issues exactly HLOADS loads - the counted vmcnt at ky=1 depends on that.  Offsets are 32-bit from the tensor base.
@@ -122,7 +138,7 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
     auto one = [&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
       if constexpr (i >= I0 && i < I1) {
-        const int px = min(max(px0 + 64 * i, 0), hpix_max);
+        const int px = min(max(px0 + (NTH / 4) * i, 0), hpix_max);
         hreg[i] = *reinterpret_cast<const u32x4 *>(p.in + (unsigned)(px * p.Cin + cc * HL_CK + (tid & 3) * 8));
       }
     };
@@ -138,49 +154,66 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
     }
   };
   // ---- weights: one kernel row (3 taps) per group, LDS-DMA, lane-linear image with the swizzle on the SOURCE ----
-  // instruction q of wave w covers tap kx = q/2, couts ((q&1)*4 + w)*16 + lane/4, 16-byte channel group lane%4 (swizzled):
-  // the lane part of the source address is the same for every q, group and chunk
+  // instruction q of wave w is 1-KB piece g = q*2*NPW + w of the 3 x 128 x 64-B image: tap kx = g/8, couts (g%8)*16 + lane/4,
+  // 16-byte channel group lane%4 (swizzled): the lane part of the source address is the same for every q, group and chunk
   const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
   auto wstage = [&](int cc, int ky, int buf, auto q0c, auto q1c) __attribute__((always_inline)) {     // DMA instructions Q0 .. Q1-1 of group (cc, ky)
     constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
 #pragma unroll
     for (int q = Q0; q < Q1; ++q) {
-      const f16 *sb = p.w + (size_t)(c0 + (q & 1) * 64) * p.Kpad + (ky * 3 + (q >> 1)) * p.Cin + cc * HL_CK;
+      constexpr int dummy_npw = NPW;
+      const int g0 = q * 2 * dummy_npw;      // piece index without the wave part (wave < 2 NPW <= 8 never carries into g/8)
+      const f16 *sb = p.w + (size_t)(c0 + (g0 & 7) * 16) * p.Kpad + (ky * 3 + (g0 >> 3)) * p.Cin + cc * HL_CK;
       glds16(sb, woff, wbuf + buf * C::WBUF_HALFS + (q * 2 * NWN + wave) * 512);
     }
   };
 
+  // accumulators start at the bias (fp32): a lane owns channels wm*64 + i*32 + rg*8 + lh*4 + (0..3) of its pixels
   floatx16 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j][rg * 4 + 0] = bv.x;
+        acc[i][j][rg * 4 + 1] = bv.y;
+        acc[i][j][rg * 4 + 2] = bv.z;
+        acc[i][j][rg * 4 + 3] = bv.w;
+      }
+    }
 
   if (tid < 1) *reinterpret_cast<u32x4 *>(&halo[C::ZERO_OFF]) = u32x4{0, 0, 0, 0};
   halo_load(0, IC<0>{}, IC<HLOADS>{});
   wstage(0, 0, 0, IC<0>{}, IC<WQ>{});
   int g = 0;
+  STAMP(unsigned long long t_wait = 0; unsigned long long t_body = 0; unsigned long long t_top = 0; unsigned long long t_prev = __builtin_amdgcn_s_memtime();)
   for (int cc = 0; cc < nchunk; ++cc) {
+    STAMP(unsigned long long tt0 = __builtin_amdgcn_s_memtime();)
     __syncthreads();          // every wave is done reading the previous chunk's halo
     halo_store();
+    STAMP(t_top += __builtin_amdgcn_s_memtime() - tt0;)
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky, ++g) {
       const int buf = g & 1;
+      STAMP(unsigned long long ta = __builtin_amdgcn_s_memtime();)
       // weights(g) must have landed and the halo stores must be visible.  The halo prefetch loads issued in
       // group ky=0 are YOUNGER than the weights needed at ky=1, so a counted vmcnt leaves them in flight there
       // (a __syncthreads() would drain them one group after issue).
       if (ky == 1 && cc + 1 < nchunk) {
-        static_assert(HLOADS == 7 || HLOADS == 5 || HLOADS == 4 || HLOADS == 3, "add the vmcnt immediate for this tile");
+        static_assert(HLOADS >= 2 && HLOADS <= 7, "add the vmcnt immediate for this tile");
         if constexpr (HLOADS == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+        else if constexpr (HLOADS == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
         else if constexpr (HLOADS == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
         else if constexpr (HLOADS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else if constexpr (HLOADS == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
+      STAMP(unsigned long long tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta;)
       __builtin_amdgcn_sched_barrier(0);
       // The next group's weights (into the other buffer) and, in group ky=0, the next chunk's halo (into registers) are
       // requested from INSIDE the MFMA steps below - two DMAs after the first MFMA pair of steps 0..2, the halo loads in
@@ -191,7 +224,7 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
         nky = 0;
         ncc = cc + 1;
       }
-      const bool more_w = ncc < nchunk, more_h = (ky == 0) && (cc + 1 < nchunk);
+      const bool more_w = ncc < nchunk && !(dbg & 2), more_h = (ky == 0) && (cc + 1 < nchunk) && !(dbg & 1);
       const f16 *wb = wbuf + buf * C::WBUF_HALFS;
       // keep the per-tap border selects INSIDE the loop: hoisted, their 72 results would not fit the register file
       unsigned vm[NT];
@@ -233,7 +266,7 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
           if (st + 1 < 6) load_b(st + 1, j);
           if (j == 0) {
             if constexpr (st < 3) {
-              if (more_w) wstage(ncc, nky, buf ^ 1, IC<2 * st>{}, IC<2 * st + 2>{});
+              if (more_w) wstage(ncc, nky, buf ^ 1, IC<(WQ / 3) * st>{}, IC<(WQ / 3) * (st + 1)>{});
             } else {
               constexpr int HP = (HLOADS + 2) / 3;
               if (more_h) halo_load(cc + 1, IC<(st - 3) * HP>{}, IC<(st - 3) * HP + HP>{});
@@ -248,71 +281,73 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
       step(IC<3>{});
       step(IC<4>{});
       step(IC<5>{});
+      STAMP(t_body += __builtin_amdgcn_s_memtime() - tb;)
     }
   }
+  STAMP(const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();)
 
   // ---------------- epilogue ----------------
-  __syncthreads();
-  f16 *stage = lds;   // [256 px][HL_SLD]
-  if (p.res) {
-    // all loads of a batch are issued before the first ds_write (a load->store loop serialises their latencies)
-    constexpr int NRES = TM * 16 / NTH, RB = NRES < 8 ? NRES : 8;
+  // RES / POST are compile-time (a runtime flag costs three branches per register quad, ~100 per wave), ReLU is a
+  // branch-free max against 0 or -inf.  The residual tile (16 x 16 B per thread, row-contiguous) is requested in ONE batch
+  // and before the barrier - the loop's fragment / halo registers are dead here - so it travels while the slower waves
+  // finish their MFMAs.
+  f16 *stage = lds;   // [TM px][HL_SLD]
+  constexpr int NRES = TM * 16 / NTH;
+  u32x4 rv[NRES];
+  if constexpr (RES) {
 #pragma unroll
-    for (int i0 = 0; i0 < NRES; i0 += RB) {
-      u32x4 rv[RB];
+    for (int u = 0; u < NRES; ++u) {
+      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
+      const int m = min(m0 + px, p.M - 1);      // unconditional (clamped) load: a guarded one makes hipcc wait per element
+      rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
+    }
+  }
+  const float lo = p.relu ? 0.f : -__builtin_inff();
+  STAMP(const unsigned long long t_e0 = __builtin_amdgcn_s_memtime();)
+  __syncthreads();          // every wave is done with the halo / weight images: the staging tile may overwrite them
+  STAMP(const unsigned long long t_e1 = __builtin_amdgcn_s_memtime();)
+  if constexpr (RES) {
 #pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
-        const int m = min(m0 + px, p.M - 1);      // unconditional (clamped) load: a guarded one makes hipcc wait per element
-        rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
-        *reinterpret_cast<u32x4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
-      }
+    for (int u = 0; u < NRES; ++u) {
+      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
+      *reinterpret_cast<u32x4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
     }
     __syncthreads();
   }
-  // bias (and, where used, positional-embedding) values are fetched in batches BEFORE they are consumed: loaded
-  // one by one inside the loop hipcc waits vmcnt(0) after every load (32 serial L2 round trips per lane)
-  float4 bvs[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) bvs[i][rg] = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
+  STAMP(const unsigned long long t_e2 = __builtin_amdgcn_s_memtime();)
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int pxl = wn * PXW + j * 32 + lr;
-    const int m = m0 + pxl;
     float4 pvs[2][4];
-    if (p.post_add) {
-      const int prow = min(m, p.M - 1) % p.post_period;
+    if constexpr (POST) {
+      const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg)
           pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
     }
+    // the 8 staged residual quads of this pixel are read in one go (a read -> write pair per quad serialises 32 LDS latencies)
+    half4 rq[2][4];
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) rq[i][rg] = *reinterpret_cast<const half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 32 + rg * 8 + lh * 4]);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int col = wm * 64 + i * 32 + rg * 8 + lh * 4;   // channel within the 128-wide tile
-        const float4 bv = bvs[i][rg];
-        float v[4] = {acc[i][j][rg * 4 + 0] + bv.x, acc[i][j][rg * 4 + 1] + bv.y, acc[i][j][rg * 4 + 2] + bv.z,
-                      acc[i][j][rg * 4 + 3] + bv.w};
-        f16 *sp = &stage[pxl * HL_SLD + col];
-        if (p.res) {
-          half4 rv = *reinterpret_cast<const half4 *>(sp);
+        float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
+        if constexpr (RES) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+          for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][rg][e];
         }
-        if (p.relu) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if (p.post_add) {
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+        if constexpr (POST) {
           const float4 pv = pvs[i][rg];
           v[0] += pv.x;
           v[1] += pv.y;
@@ -322,11 +357,13 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
         half4 hv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
-        *reinterpret_cast<half4 *>(sp) = hv;
+        *reinterpret_cast<half4 *>(&stage[pxl * HL_SLD + col]) = hv;
       }
     }
   }
+  STAMP(const unsigned long long t_e3 = __builtin_amdgcn_s_memtime();)
   __syncthreads();
+  STAMP(const unsigned long long t_e4 = __builtin_amdgcn_s_memtime();)
   constexpr int NOUT = TM * 16 / NTH, OB = NOUT < 8 ? NOUT : 8;
 #pragma unroll
   for (int i0 = 0; i0 < NOUT; i0 += OB) {
@@ -348,25 +385,37 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
       }
     }
   }
+  STAMP(if (lane == 0 && blockIdx.x < 4096) {
+    unsigned long long *o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+    if (dbg & 4) { t_wait = ((t_e0 - t_loop_end) << 32) | (t_e1 - t_e0); t_body = ((t_e2 - t_e1) << 32) | (t_e3 - t_e2); t_top = (t_e4 - t_e3); }
+    o[0] = t_wait; o[1] = t_body; o[2] = t_top | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);   /* HW_ID in the high half */ o[3] = t_loop_end - t_prev; o[4] = t_prev - t_entry;
+    o[5] = __builtin_amdgcn_s_memtime() - t_loop_end; o[6] = r_entry; o[7] = __builtin_amdgcn_s_memrealtime();
+  })
 }
 
-// Grid = n_main workgroups of 256 px x 128 co, then n_tail4 workgroups of 64 px x 128 co covering the LAST main-size tiles
-// cut in four.  With two workgroups resident per CU a launch has 512 slots; 3150 equal tiles (N=252: every layer of the
-// network) would leave 84 % of the chip idle for the whole seventh round - cutting only the remainder into quarters lets
-// that round end after a quarter of the time.  (Cutting every tile would cost the big tile's operand reuse.)
-template <int W>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(ConvArgs p, int n_main) {
+// Grid = n_main workgroups of 128 NPW px x 128 co, then n_tail4 workgroups of 32 NPW px x 128 co covering the LAST main-size
+// tiles cut in four.  A launch has (workgroups per CU) x 256 slots; at N=252 every layer of the network has 3150 or 1576
+// 256-pixel tiles, i.e. a last round that is 8-15 % full - cutting only that remainder into quarters lets the round end
+// after a fraction of the time.  (Cutting every tile would cost the big tile's operand reuse.)
+//
+// NPW = 4 (8 waves, 512 px x 128 co, ONE workgroup per CU) is the default: every byte of the weight image that streams
+// through LDS-DMA then feeds twice as many MFMAs as with two independent 256-pixel workgroups per CU, and that stream
+// (not the MFMA pipe) is what bounds the 4-wave form: with the weight DMA switched off it runs 30 % faster, with the
+// halo loads switched off 6 %.
+template <int W, int NPW, bool RES, bool POST>
+__global__ __launch_bounds__(128 * NPW, NPW == 2 ? 2 : 1) void conv3x3_halo_kernel(ConvArgs p, int n_main, int dbg) {
   extern __shared__ __attribute__((aligned(16))) f16 lds[];
+  constexpr int TMM = 128 * NPW;
   const int n_ct = p.Cout / HL_BM;
   if ((int)blockIdx.x < n_main) {
     const int L = xcd_remap(blockIdx.x, n_main);   // consecutive L = cout tiles of one pixel tile, then the next pixel tile
-    halo_tile<W, 4>(p, (L / n_ct) * HL_TM, (L % n_ct) * HL_BM, lds);
+    halo_tile<W, 4, NPW, RES, POST>(p, (L / n_ct) * TMM, (L % n_ct) * HL_BM, lds, dbg);
   } else {
     const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
     const int L = n_main + (t >> 2);
-    const int m0 = (L / n_ct) * HL_TM + (t & 3) * 64;
+    const int m0 = (L / n_ct) * TMM + (t & 3) * (TMM / 4);
     if (m0 >= p.M) return;
-    halo_tile<W, 1>(p, m0, (L % n_ct) * HL_BM, lds);
+    halo_tile<W, 1, NPW, RES, POST>(p, m0, (L % n_ct) * HL_BM, lds, dbg);
   }
 }
 
@@ -376,6 +425,7 @@ bool conv_halo_supported(const ConvArgs &a) {
 }
 
 int g_halo_tail = 1;   // FP_HALO_TAIL=0 disables the tail split (A/B timing only; results are identical)
+int g_halo_npw = 4;    // FP_HALO_NPW=2 selects the 4-wave / 2-workgroups-per-CU form (A/B timing only; results are identical)
 
 // main/tail split: whole rounds of `slots` main tiles stay; the remainder is cut in four when that shortens the last round
 // (a quarter tile costs ~0.35 of a main tile: less operand reuse), i.e. when the remainder fills < ~70 % of a round.
@@ -391,28 +441,36 @@ static void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
   }
 }
 
-template <int W>
+template <int W, int NPW, bool RES, bool POST>
 static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
-  using C = HaloCfg<W>;
+  constexpr int TMM = 128 * NPW;
+  using C = HaloCfg<W, TMM>;
   static bool attr_set = false;
   static int slots = 512;
+  static int dbg = getenv("FP_HALO_DBG") ? atoi(getenv("FP_HALO_DBG")) : 0;   // experiment: 1 = no halo reloads, 2 = no weight reloads (wrong results)
   if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W, NPW, RES, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     int dev = 0, cus = 256;
     FP_CHECK_HIP(hipGetDevice(&dev));
     FP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    slots = 2 * cus;
+    slots = (NPW == 2 ? 2 : 1) * cus;
     attr_set = true;
   }
-  const int n_tiles = ((a.M + HL_TM - 1) / HL_TM) * (a.Cout / HL_BM);
+  const int n_tiles = ((a.M + TMM - 1) / TMM) * (a.Cout / HL_BM);
   int n_main, n_tail4;
   halo_split(n_tiles, slots, &n_main, &n_tail4);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<W>), dim3(n_main + n_tail4), dim3(256), C::LDS_BYTES, s, a, n_main);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<W, NPW, RES, POST>), dim3(n_main + n_tail4), dim3(128 * NPW), C::LDS_BYTES, s, a, n_main, dbg);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
 
+template <int W, int NPW>
+static int launch_halo_flags(const ConvArgs &a, hipStream_t s) {
+  if (a.post_add) return a.res ? launch_halo_w<W, NPW, true, true>(a, s) : launch_halo_w<W, NPW, false, true>(a, s);
+  return a.res ? launch_halo_w<W, NPW, true, false>(a, s) : launch_halo_w<W, NPW, false, false>(a, s);
+}
+
 int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
-  if (a.W == 40) return launch_halo_w<40>(a, s);
-  return launch_halo_w<20>(a, s);
+  if (g_halo_npw == 2) return a.W == 40 ? launch_halo_flags<40, 2>(a, s) : launch_halo_flags<20, 2>(a, s);
+  return a.W == 40 ? launch_halo_flags<40, 4>(a, s) : launch_halo_flags<20, 4>(a, s);
 }
