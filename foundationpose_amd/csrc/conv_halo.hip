@@ -260,8 +260,20 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
+#ifdef HALO_MFMA16_EXPERIMENT
+          // timing experiment only (wrong results): the same operand traffic and MFMA cycles issued as 16x16x32 instructions
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            floatx4 q0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, q1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
+            q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][i], bf[j], q0, 0, 0, 0);
+            q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][i], bf[j], q1, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = q0[e], acc[i][j][4 + e] = q1[e];
+          }
+#else
           acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][0], bf[j], acc[0][j], 0, 0, 0);
           acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][1], bf[j], acc[1][j], 0, 0, 0);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           if (st + 1 < 6) load_b(st + 1, j);
           if (j == 0) {
