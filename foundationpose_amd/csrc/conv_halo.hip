@@ -260,20 +260,8 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-#ifdef HALO_MFMA16_EXPERIMENT
-          // timing experiment only (wrong results): the same operand traffic and MFMA cycles issued as 16x16x32 instructions
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            floatx4 q0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]}, q1 = {acc[i][j][4], acc[i][j][5], acc[i][j][6], acc[i][j][7]};
-            q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][i], bf[j], q0, 0, 0, 0);
-            q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][i], bf[j], q1, 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = q0[e], acc[i][j][4 + e] = q1[e];
-          }
-#else
           acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][0], bf[j], acc[0][j], 0, 0, 0);
           acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][1], bf[j], acc[1][j], 0, 0, 0);
-#endif
           __builtin_amdgcn_sched_barrier(0);
           if (st + 1 < 6) load_b(st + 1, j);
           if (j == 0) {
@@ -405,6 +393,308 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
   })
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// DEFAULT FORM.  8-wave tile (512 px x 128 co, one workgroup per CU) with the halo band staged by LDS-DMA as well, double
+// buffered, on v_mfma_f32_16x16x32_f16 (same FLOPs per LDS byte and per MFMA-pipe cycle as 32x32x16):
+//   * halo pixels are 64 bytes, UNPADDED (so a DMA instruction's 64 lanes x 16 B land linearly: 16 pixels x 4 channel groups);
+//     bank conflicts are avoided by an XOR swizzle instead: pixel P keeps channel group c at position c ^ ((P >> 2) & 3),
+//     applied on the SOURCE address of the DMA (the destination of an LDS-DMA is always lane-linear);
+//   * no staging registers, no ds_write of the band, no barrier pair at the top of a chunk: the band of chunk cc+1 streams
+//     into the other buffer while chunk cc is multiplied, one DMA instruction per pixel-tile visit;
+//   * fragment geometry: lane r of a 16-pixel tile holds pixel PI2(r), with the pixels of
+//     lanes {0-3,12-15} in residues {0,1} mod 4 and those of lanes {4-11} in residues {2,3} - then the four pixels of one
+//     residue class inside a ds_read_b128 lane group always carry four different swizzle values, for any tile alignment;
+//     lane quarter q supplies channel group q; weight rows are swizzled by 2*((co>>3)&1).
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int halo_pi2(int r) {
+  const int k = (r < 4) ? r : (r < 12 ? r - 4 : r - 8);        // index 0..7 inside the lane's residue half
+  return (r >= 4 && r < 12) ? (k >> 1) * 4 + 2 + (k & 1) : (k >> 1) * 4 + (k & 1);
+}
+
+template <int W, int TM>
+struct HaloCfgD {
+  static constexpr int MAXSLOT = (W - 1 + TM - 1) / W + 1 + 2;
+  static constexpr int NB = MAXSLOT * W + 2;                       // band pixels in use (pixel p at index p+1)
+  static constexpr int HQ = ((NB + 15) / 16 + 7) / 8;              // halo DMA instructions per wave per chunk (8 waves)
+  static constexpr int BPX = HQ * 8 * 16;                          // band pixels allocated
+  static constexpr int HBUF_HALFS = BPX * 32;
+  static constexpr int ZERO_OFF = 2 * HBUF_HALFS;                  // half offset of the zero chunk
+  static constexpr int WBUF_OFF = ZERO_OFF + 8;
+  static constexpr int WBUF_HALFS = 3 * HL_BM * HL_CK;
+  static constexpr int LDS_HALFS_MAIN = WBUF_OFF + 2 * WBUF_HALFS;
+  static constexpr int LDS_HALFS_EPI = TM * HL_SLD;
+  static constexpr int LDS_BYTES = 2 * (LDS_HALFS_MAIN > LDS_HALFS_EPI ? LDS_HALFS_MAIN : LDS_HALFS_EPI);
+};
+
+template <int W, int NT, bool RES, bool POST>
+__device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, const int c0, f16 *lds) {
+  constexpr int NPW = 4, TM = 32 * NT * NPW;
+  using C = HaloCfgD<W, TM>;
+  constexpr int H = W;
+  constexpr int NTH = 128 * NPW;        // threads
+  constexpr int PXW = 32 * NT;          // pixels per wave
+  constexpr int NJ = 2 * NT;            // 16-pixel tiles per wave
+  constexpr int HQ = C::HQ;
+  constexpr int WQ = 24 / (2 * NPW);    // weight DMA instructions per wave per group
+  f16 *wbuf = lds + C::WBUF_OFF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NPW, wn = wave % NPW;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int pr = halo_pi2(r16);
+  const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by band row 0
+  const int total_rows = p.Nimg * H;
+  const int nchunk = p.Cin / HL_CK;
+
+  // ---- B fragments: band index of the top-left tap of this lane's pixel in tile 0 (tile j, taps: see load_b) ----
+  const int pb = m0 + wn * PXW + pr - GR0 * W - W;
+  unsigned vmp[(NJ + 2) / 3];          // 9 validity bits (ky*3+kx) per pixel tile, three tiles per register
+#pragma unroll
+  for (int t = 0; t < (NJ + 2) / 3; ++t) vmp[t] = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int m = min(m0 + wn * PXW + j * 16 + pr, p.M - 1);
+    const int gr = m / W, ox = m - gr * W, oy = gr % H;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) vmp[j / 3] |= 1u << ((j % 3) * 9 + ky * 3 + kx);
+      }
+  }
+  // ---- A fragments: row co = wm*64 + i*16 + r16 (i, tap: immediates); swizzle 2*((co>>3)&1) = 2*(r16>>3) for every i
+  const int wa = (wm * 64 + r16) * 32 + ((q4 ^ ((r16 >> 3) << 1)) * 8);
+
+  // ---- halo band by LDS-DMA: instruction h of wave w lands band pixels (h*8 + w)*16 .. +15, lane i = (pixel i/4, position i%4)
+  const int hpix_max = total_rows * W - 1;
+  auto halo_dma = [&](int cc, int hb, auto hc) __attribute__((always_inline)) {
+    constexpr int h = decltype(hc)::value;
+    int l4 = lane >> 2;
+    asm volatile("" : "+v"(l4));                    // recompute per use: six hoisted offsets would cost six registers
+    const int P = (h * 8 + wave) * 16 + l4;
+    const int c = (lane & 3) ^ ((P >> 2) & 3);
+    const int gp = min(max(GR0 * W + P - 1, 0), hpix_max);      // clamped: what lands for rows outside the tensor is never read
+    const unsigned off = (unsigned)(gp * p.Cin + cc * HL_CK + c * 8) * 2u;
+    glds16(p.in, off, lds + hb * C::HBUF_HALFS + (h * 8 + wave) * 512);
+  };
+  // ---- weights (as in halo_tile) with this form's swizzle: row (g%8)*16 + lane/4 -> bit 3 of the row = (lane>>5)&1
+  const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ (((lane >> 5) & 1) << 1)) * 8)) * 2);
+  auto wstage = [&](int cc, int ky, int buf, auto q0c, auto q1c) __attribute__((always_inline)) {
+    constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+      const int g0 = q * 2 * NPW;
+      const f16 *sb = p.w + (size_t)(c0 + (g0 & 7) * 16) * p.Kpad + (ky * 3 + (g0 >> 3)) * p.Cin + cc * HL_CK;
+      glds16(sb, woff, wbuf + buf * C::WBUF_HALFS + (q * 2 * NPW + wave) * 512);
+    }
+  };
+
+  // accumulators start at the bias: a lane owns channels wm*64 + i*16 + q4*4 + (0..3) of pixel PI2(r16) of each tile
+  floatx4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 16 + q4 * 4);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = floatx4{bv.x, bv.y, bv.z, bv.w};
+  }
+
+  if (tid < 1) *reinterpret_cast<u32x4 *>(&lds[C::ZERO_OFF]) = u32x4{0, 0, 0, 0};
+  {
+    auto all = [&](auto hc) __attribute__((always_inline)) {
+      if constexpr (decltype(hc)::value < HQ) halo_dma(0, 0, hc);
+    };
+    all(IC<0>{}), all(IC<1>{}), all(IC<2>{}), all(IC<3>{}), all(IC<4>{}), all(IC<5>{}), all(IC<6>{}), all(IC<7>{});
+    static_assert(HQ <= 8, "extend the list");
+  }
+  wstage(0, 0, 0, IC<0>{}, IC<WQ>{});
+  int g = 0;
+  for (int cc = 0; cc < nchunk; ++cc) {
+    const f16 *halo = lds + (cc & 1) * C::HBUF_HALFS;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky, ++g) {
+      const int buf = g & 1;
+      // weights(g) - and at ky=0 the band of this chunk - must have landed.  The band DMAs of the NEXT chunk, issued in
+      // group ky=0, are younger than the weights needed at ky=1: a counted vmcnt leaves them in flight there.
+      if (ky == 1 && cc + 1 < nchunk) {
+        static_assert(HQ >= 2 && HQ <= 6, "add the vmcnt immediate for this tile");
+        if constexpr (HQ == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else if constexpr (HQ == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else if constexpr (HQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else if constexpr (HQ == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      int ncc = cc, nky = ky + 1;
+      if (nky == 3) {
+        nky = 0;
+        ncc = cc + 1;
+      }
+      const bool more_w = ncc < nchunk, more_h = (ky == 0) && (cc + 1 < nchunk);
+      const f16 *wb = wbuf + buf * C::WBUF_HALFS;
+      unsigned vm[(NJ + 2) / 3];           // keep the border selects inside the loop (see halo_tile)
+#pragma unroll
+      for (int t = 0; t < (NJ + 2) / 3; ++t) {
+        vm[t] = vmp[t];
+        asm volatile("" : "+v"(vm[t]));
+      }
+      // 3 steps (kx) x NJ pixel tiles = 3 NJ tile visits, 4 MFMAs each; pixel fragments rotate through BD registers (the
+      // fragment of visit t+BD is requested right after the MFMAs of visit t), weight fragments of step st+1 go to the spare
+      // set at the start of step st.  The tap's swizzle term is the same for all tiles of a step (tiles are 16 pixels apart).
+      constexpr int NV = 3 * NJ, BD = NJ < 4 ? NJ : 4;
+      half8 af[2][4], bf[BD];
+      int tapb[3];                         // half offset of (tap pixel, channel group q4) of tile 0, per kx
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int Pt = pb + ky * W + kx;
+        tapb[kx] = Pt * 32 + ((q4 ^ ((Pt >> 2) & 3)) * 8);
+      }
+      auto load_a = [&](int kx, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const half8 *>(&wb[wa + i * (16 * 32) + kx * (HL_BM * HL_CK)]);
+      };
+      auto load_b = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value, kx = t / NJ, j = t % NJ;
+        constexpr int imm = j * 16 * 32;
+        const bool ok = (vm[j / 3] >> ((j % 3) * 9 + ky * 3 + kx)) & 1u;
+        const int base = ok ? tapb[kx] : (C::ZERO_OFF - (cc & 1) * C::HBUF_HALFS - imm);
+        bf[t % BD] = *reinterpret_cast<const half8 *>(&halo[base + imm]);
+      };
+      load_a(0, 0);
+      load_b(IC<0>{});
+      if constexpr (BD > 1) load_b(IC<1>{});
+      if constexpr (BD > 2) load_b(IC<2>{});
+      if constexpr (BD > 3) load_b(IC<3>{});
+      __builtin_amdgcn_sched_barrier(0);
+      auto visit = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value, st = t / NJ, j = t % NJ, cur = st & 1;
+        if constexpr (j == 0 && st + 1 < 3) {
+          load_a(st + 1, cur ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][i], bf[t % BD], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (t + BD < NV) load_b(IC<t + BD>{});
+        // weight DMAs of the next group after the first visits; the next chunk's band DMAs after them, from visit NJ on
+        // (program order "weights, then band": the counted vmcnt at ky=1 relies on it)
+        constexpr int DQ = (WQ + NJ - 1) / NJ, HV = (HQ + (NV - NJ) - 1) / (NV - NJ);
+        static_assert(HV == 1, "one band DMA per visit");
+        if constexpr (t * DQ < WQ) {
+          if (more_w) wstage(ncc, nky, buf ^ 1, IC<t * DQ>{}, IC<((t + 1) * DQ < WQ ? (t + 1) * DQ : WQ)>{});
+        } else if constexpr (t >= NJ && t - NJ < HQ) {
+          if (more_h) halo_dma(cc + 1, (cc + 1) & 1, IC<t - NJ>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+#define V4(a) visit(IC<(a) < NV ? (a) : NV - 1>{}); if constexpr ((a) + 1 < NV) visit(IC<(a) + 1 < NV ? (a) + 1 : NV - 1>{}); if constexpr ((a) + 2 < NV) visit(IC<(a) + 2 < NV ? (a) + 2 : NV - 1>{}); if constexpr ((a) + 3 < NV) visit(IC<(a) + 3 < NV ? (a) + 3 : NV - 1>{});
+      V4(0) if constexpr (NV > 4) { V4(4) } if constexpr (NV > 8) { V4(8) V4(12) V4(16) V4(20) }
+#undef V4
+      static_assert(NV == 6 || NV == 24, "visit list covers NJ = 2 and NJ = 8");
+    }
+  }
+
+  // ---------------- epilogue (as in halo_tile; a lane holds 4 consecutive channels of ONE pixel per accumulator) ----------------
+  f16 *stage = lds;   // [TM px][HL_SLD]
+  constexpr int NRES = TM * 16 / NTH;
+  u32x4 rv[NRES];
+  if constexpr (RES) {
+#pragma unroll
+    for (int u = 0; u < NRES; ++u) {
+      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
+      const int m = min(m0 + px, p.M - 1);
+      rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
+    }
+  }
+  const float lo = p.relu ? 0.f : -__builtin_inff();
+  __syncthreads();          // every wave is done with the band / weight images: the staging tile may overwrite them
+  if constexpr (RES) {
+#pragma unroll
+    for (int u = 0; u < NRES; ++u) {
+      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
+      *reinterpret_cast<u32x4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int pxl = wn * PXW + j * 16 + pr;
+    float4 pvs[4];
+    if constexpr (POST) {
+      const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pvs[i] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * 64 + i * 16 + q4 * 4);
+    }
+    half4 rq[4];
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rq[i] = *reinterpret_cast<const half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 16 + q4 * 4]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if constexpr (RES) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+      if constexpr (POST) {
+        v[0] += pvs[i].x;
+        v[1] += pvs[i].y;
+        v[2] += pvs[i].z;
+        v[3] += pvs[i].w;
+      }
+      half4 hv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
+      *reinterpret_cast<half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 16 + q4 * 4]) = hv;
+    }
+  }
+  __syncthreads();
+  constexpr int NOUT = TM * 16 / NTH, OB = NOUT < 8 ? NOUT : 8;
+#pragma unroll
+  for (int i0 = 0; i0 < NOUT; i0 += OB) {
+    u32x4 ov[OB];
+#pragma unroll
+    for (int u = 0; u < OB; ++u) {
+      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
+      ov[u] = *reinterpret_cast<const u32x4 *>(&stage[px * HL_SLD + c16 * 8]);
+    }
+#pragma unroll
+    for (int u = 0; u < OB; ++u) {
+      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
+      const int m = m0 + px;
+      if (m < p.M) {
+        const bool hi = m >= p.split_m;
+        const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+        const int coff = hi ? p.coff_hi : 0;
+        *reinterpret_cast<u32x4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
+      }
+    }
+  }
+}
+
+template <int W, bool RES, bool POST>
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_d16_kernel(ConvArgs p, int n_main) {
+  extern __shared__ __attribute__((aligned(16))) f16 lds[];
+  constexpr int TMM = 512;
+  const int n_ct = p.Cout / HL_BM;
+  if ((int)blockIdx.x < n_main) {
+    const int L = xcd_remap(blockIdx.x, n_main);
+    halo_tile_d16<W, 4, RES, POST>(p, (L / n_ct) * TMM, (L % n_ct) * HL_BM, lds);
+  } else {
+    const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
+    const int L = n_main + (t >> 2);
+    const int m0 = (L / n_ct) * TMM + (t & 3) * (TMM / 4);
+    if (m0 >= p.M) return;
+    halo_tile_d16<W, 1, RES, POST>(p, m0, (L % n_ct) * HL_BM, lds);
+  }
+}
+
+
 // Grid = n_main workgroups of 128 NPW px x 128 co, then n_tail4 workgroups of 32 NPW px x 128 co covering the LAST main-size
 // tiles cut in four.  A launch has (workgroups per CU) x 256 slots; at N=252 every layer of the network has 3150 or 1576
 // 256-pixel tiles, i.e. a last round that is 8-15 % full - cutting only that remainder into quarters lets the round end
@@ -476,13 +766,43 @@ static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
   return FP_OK;
 }
 
+int g_halo_m16 = 1;    // FP_HALO_MFMA=32 selects the 32x32x16 register-staged form (A/B timing; results differ in the last bits only)
+
 template <int W, int NPW>
 static int launch_halo_flags(const ConvArgs &a, hipStream_t s) {
   if (a.post_add) return a.res ? launch_halo_w<W, NPW, true, true>(a, s) : launch_halo_w<W, NPW, false, true>(a, s);
   return a.res ? launch_halo_w<W, NPW, true, false>(a, s) : launch_halo_w<W, NPW, false, false>(a, s);
 }
 
+template <int W, bool RES, bool POST>
+static int launch_halo_d16(const ConvArgs &a, hipStream_t s) {
+  using C = HaloCfgD<W, 512>;
+  static_assert(HaloCfgD<W, 128>::LDS_BYTES <= C::LDS_BYTES, "tail tiles fit the main tile's LDS");
+  static bool attr_set = false;
+  static int slots = 256;
+  if (!attr_set) {
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_d16_kernel<W, RES, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    int dev = 0;
+    FP_CHECK_HIP(hipGetDevice(&dev));
+    FP_CHECK_HIP(hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev));
+    attr_set = true;
+  }
+  const int n_tiles = ((a.M + 511) / 512) * (a.Cout / HL_BM);
+  int n_main, n_tail4;
+  halo_split(n_tiles, slots, &n_main, &n_tail4);
+  hipLaunchKernelGGL((conv3x3_halo_d16_kernel<W, RES, POST>), dim3(n_main + n_tail4), dim3(512), C::LDS_BYTES, s, a, n_main);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+template <int W>
+static int launch_halo_d16_flags(const ConvArgs &a, hipStream_t s) {
+  if (a.post_add) return a.res ? launch_halo_d16<W, true, true>(a, s) : launch_halo_d16<W, false, true>(a, s);
+  return a.res ? launch_halo_d16<W, true, false>(a, s) : launch_halo_d16<W, false, false>(a, s);
+}
+
 int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
+  if (g_halo_m16) return a.W == 40 ? launch_halo_d16_flags<40>(a, s) : launch_halo_d16_flags<20>(a, s);
   if (g_halo_npw == 2) return a.W == 40 ? launch_halo_flags<40, 2>(a, s) : launch_halo_flags<20, 2>(a, s);
   return a.W == 40 ? launch_halo_flags<40, 4>(a, s) : launch_halo_flags<20, 4>(a, s);
 }
