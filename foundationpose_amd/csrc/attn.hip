@@ -18,8 +18,28 @@
 #define FA_KB 64                // keys per pipeline stage
 #define FA_STAGE_HALFS (FA_KB * AT_DH * 2)   // K block [64][128] + V^T block [128][64]
 
+// LDS-DMA from inline asm (see conv_halo.hip: through the builtin, hipcc turns every later LDS-read wait into lgkmcnt(0));
+// completion is waited for by the explicit s_waitcnt vmcnt(n) in front of the barriers of the key loop.
 __device__ __forceinline__ void at_glds16(const f16 *g, f16 *l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)l);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");
+}
+
+// The transposed V image [b][4][128][416] is padded from 400 to 416 tokens; the V projection writes tokens < T only, the
+// pad must read as zero (P^T carries exact zeros there, but 0 x NaN from stale arena bytes would poison O).  Zeroing just
+// the pad columns replaces a memset of the whole 107-MB image per attention call.
+__global__ void vt_pad_zero_kernel(f16 *__restrict__ vt, int rows, int T) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  for (int t = T; t < AT_TP; ++t) vt[(size_t)r * AT_TP + t] = (f16)0.f;
+}
+
+int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s) {
+  const int rows = B * 4 * AT_DH;
+  if (rows == 0 || T >= AT_TP) return FP_OK;
+  hipLaunchKernelGGL(vt_pad_zero_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, vt, rows, T);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
 }
 
 // Flash-style multi-head self-attention core (400 tokens, 4 heads x 128) on v_mfma_f32_32x32x16_f16.

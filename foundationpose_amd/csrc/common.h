@@ -139,6 +139,7 @@ struct ConvArgs {
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
 int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s);
+int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s);
 int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
 int launch_layernorm_h(const f16 *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
 int launch_ln_mean_head_h(const f16 *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,

@@ -436,6 +436,7 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
   constexpr int NJ = 2 * NT;            // 16-pixel tiles per wave
   constexpr int HQ = C::HQ;
   constexpr int WQ = 24 / (2 * NPW);    // weight DMA instructions per wave per group
+  STAMP(const unsigned long long t_entry = __builtin_amdgcn_s_memtime(); const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();)
   f16 *wbuf = lds + C::WBUF_OFF;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NPW, wn = wave % NPW;
@@ -508,11 +509,13 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
   }
   wstage(0, 0, 0, IC<0>{}, IC<WQ>{});
   int g = 0;
+  STAMP(unsigned long long t_wait = 0; unsigned long long t_body = 0; unsigned long long t_prev = __builtin_amdgcn_s_memtime();)
   for (int cc = 0; cc < nchunk; ++cc) {
     const f16 *halo = lds + (cc & 1) * C::HBUF_HALFS;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky, ++g) {
       const int buf = g & 1;
+      STAMP(unsigned long long ta = __builtin_amdgcn_s_memtime();)
       // weights(g) - and at ky=0 the band of this chunk - must have landed.  The band DMAs of the NEXT chunk, issued in
       // group ky=0, are younger than the weights needed at ky=1: a counted vmcnt leaves them in flight there.
       if (ky == 1 && cc + 1 < nchunk) {
@@ -526,6 +529,7 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
+      STAMP(unsigned long long tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta;)
       __builtin_amdgcn_sched_barrier(0);
       int ncc = cc, nky = ky + 1;
       if (nky == 3) {
@@ -593,8 +597,10 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
       V4(0) if constexpr (NV > 4) { V4(4) } if constexpr (NV > 8) { V4(8) V4(12) V4(16) V4(20) }
 #undef V4
       static_assert(NV == 6 || NV == 24, "visit list covers NJ = 2 and NJ = 8");
+      STAMP(t_body += __builtin_amdgcn_s_memtime() - tb;)
     }
   }
+  STAMP(const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();)
 
   // ---------------- epilogue (as in halo_tile; a lane holds 4 consecutive channels of ONE pixel per accumulator) ----------------
   f16 *stage = lds;   // [TM px][HL_SLD]
@@ -675,6 +681,11 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
       }
     }
   }
+  STAMP(if (lane == 0 && blockIdx.x < 4096) {
+    unsigned long long *o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = t_wait; o[1] = t_body; o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32; o[3] = t_loop_end - t_prev; o[4] = t_prev - t_entry;
+    o[5] = __builtin_amdgcn_s_memtime() - t_loop_end; o[6] = r_entry; o[7] = __builtin_amdgcn_s_memrealtime();
+  })
 }
 
 template <int W, bool RES, bool POST>

@@ -361,7 +361,7 @@ int run_mha_core(fp_ctx *ctx, const ConvW &qkw, const ConvW &vw, const f16 *tok,
   const int M = N * 400;
   Conv2dCall c;
   c = Conv2dCall{tok, M, 1, 1, &qkw}; c.relu = 0; c.out = qk; FP_TRY(run_conv(ctx, c, s));
-  FP_CHECK_HIP(hipMemsetAsync(vt, 0, (size_t)N * 4 * 128 * 416 * sizeof(f16), s));
+  FP_TRY(launch_vt_pad_zero(vt, N, 400, s));
   c = Conv2dCall{tok, M, 1, 1, &vw}; c.relu = 0; c.out = vt; c.out_mode = 2; c.tokens = 400; FP_TRY(run_conv(ctx, c, s));
   return launch_attention(ctx, qk, vt, N, 400, att, s);
 }
