@@ -1,22 +1,18 @@
 // 3x3 / stride-1 / pad-1 convolution for gfx950 with the input HALO BAND resident in LDS.
 //
 // 93 % of the network FLOPs are 3x3 stride-1 convolutions on 40x40 (C=128|256) and 20x20 (C=512) maps
-// (learning/models/network_modules.py:73-111 via refine_network.py:37-50).  An im2col-style implicit
-// GEMM re-fetches every activation 9 times (once per tap) from L2 into LDS; at a 128x128 tile that is
-// 64 FLOP per LDS-fill byte, i.e. >30 TB/s of L2->LDS traffic at the MFMA peak.  Here a workgroup owns
-// 256 consecutive output pixels (flattened over images: 6.4 rows of a 40-wide map, 12.8 rows of a
-// 20-wide one) x 128 output channels and, per 32-channel input chunk,
-//   * loads the input rows it needs ONCE into LDS ("halo band": <= 10 x 40 or 16 x 20 pixels x 32 ch,
-//     24-26 KB, global -> registers (prefetched one chunk ahead under the MFMAs) -> ds_write_b128),
-//   * streams the 3 taps of one kernel row of weights at a time (128 co x 32 ci x 3 = 24 KB, double
-//     buffered) with LDS-DMA (global_load_lds_dwordx4: no VGPRs, in flight across the MFMA block),
-//   * and feeds v_mfma_f32_32x32x16_f16 for all 9 taps from that one band: the tap shift is just a
-//     different LDS address per lane (+-1 pixel, +-1 row; image borders select a zero chunk).
-// => 190 FLOP per LDS-fill byte, 48 MFMAs per wave between barriers, 2 workgroups per CU (81.3 KB LDS,
-// 4 waves each, each wave 64 co x 128 px = 2x4 accumulator tiles).  Halo pixels are padded to 80 B and the
-// weight image is XOR-swizzled, so both ds_read_b128 fragment reads are bank-conflict free.
-// Epilogue: bias (+ residual staged through LDS) + ReLU (+ positional embedding) in fp32, one rounding
-// to fp16, LDS transpose, 16-byte row-contiguous NHWC stores.
+// (learning/models/network_modules.py:73-111 via refine_network.py:37-50).  An im2col-style implicit GEMM re-fetches every
+// activation 9 times (once per tap) from L2 into LDS.  Here a workgroup owns a run of consecutive output pixels (flattened
+// over images) x 128 output channels and, per 32-channel input chunk,
+//   * brings the input rows it needs ONCE into LDS (the "halo band") and feeds all 9 taps from it: a tap shift is just a
+//     different LDS address per lane (+-1 pixel, +-1 row; taps outside the image select a zero chunk),
+//   * streams the 3 taps of one kernel row of weights at a time (128 co x 32 ci x 3 = 24 KB, double buffered) by LDS-DMA.
+// Two forms live in this file (same results up to the last bits of the fp32 accumulation order):
+//   conv3x3_halo_d16_kernel  DEFAULT: 8 waves, 512 px, band by LDS-DMA (double buffered), v_mfma_f32_16x16x32_f16;
+//   conv3x3_halo_kernel      FP_HALO_MFMA=32: 4 or 8 waves, band through registers + ds_write, v_mfma_f32_32x32x16_f16
+//                            (also carries the in-kernel cycle stamps of the diagnostic build, make -B EXTRA=-DHALO_STAMP).
+// Epilogue: accumulators start at the bias; residual (staged through LDS) + ReLU (+ positional embedding) in fp32, one
+// rounding to fp16, LDS transpose, 16-byte row-contiguous NHWC stores.
 #include "common.h"
 #include <cstdlib>
 
