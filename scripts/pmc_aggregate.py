@@ -1,0 +1,53 @@
+"""gpurun_out/pmc_traffic/{fetch,write}/*_counter_collection.csv  ->  profiles/r01_pmc_hbm_traffic.csv (+ r01_halo_traffic.json).
+
+FETCH_SIZE / WRITE_SIZE are reported in KB.  On gfx950 FETCH_SIZE counts a 128-byte request of a 16-B/lane stream as 64 B:
+it is doubled here (MI355X_MICROARCH.md); WRITE_SIZE is taken as is.  Infinity-Cache hits are part of FETCH_SIZE, so the sum
+is fabric (L2-miss) traffic - an upper bound on HBM bytes."""
+import collections, csv, glob, json, os
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(kind, counter):
+  f = glob.glob(os.path.join(REPO, 'gpurun_out', 'pmc_traffic', kind, '*_counter_collection.csv'))[0]
+  agg = collections.defaultdict(list)
+  for r in csv.DictReader(open(f)):
+    if r['Counter_Name'] == counter:
+      agg[(r['Kernel_Name'], r['Grid_Size'])].append(float(r['Counter_Value']))
+  return agg
+
+
+def main():
+  fetch, write = load('fetch', 'FETCH_SIZE'), load('write', 'WRITE_SIZE')
+  rows = []
+  for key in sorted(fetch, key=lambda k: -sum(fetch[k])):
+    name, grid = key
+    fv, wv = fetch[key], write.get(key, [0.0])
+    rows.append((name.split('(')[0][:90], grid, len(fv), sum(fv) / len(fv), 2 * sum(fv) / len(fv) / 1e3, sum(wv) / len(wv) / 1e3))
+  out = os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.csv')
+  with open(out, 'w') as f:
+    f.write('kernel,grid_threads,launches,FETCH_SIZE_KB_raw_mean,fetch_MB_corrected_x2,WRITE_SIZE_MB_mean\n')
+    for r in rows:
+      f.write('"%s",%s,%d,%.0f,%.1f,%.1f\n' % r)
+  halo = [r for r in rows if 'conv3x3_halo' in r[0]]
+  n = sum(r[2] for r in halo)
+  fe = sum(r[4] * r[2] for r in halo) / n * 1e6
+  wr = sum(r[5] * r[2] for r in halo) / n * 1e6
+  # algorithmic bytes per launch, mean over the 12 stride-1 3x3 layers of a pass at N=252: input + output (+ residual) + weights
+  X = 252 * 1600 * 512.0            # bytes of one fp16 activation tensor of the trunk: 206 MB at every resolution
+  algo = (4 * (2 * X) + 2 * X        # C=128 (504 images): 4 convs in+out, 2 residual reads
+          + 4 * (2 * X) + 2 * X      # C=256
+          + 4 * X + X                # C=512 (tensors are X/2)
+          + 4 * 9 * (128 * 128 + 256 * 256 + 512 * 512) * 2.0) / 12
+  js = {'per': 'launch (mean over the stride-1 3x3 convolutions of one bench step, N=252)', 'unit': 'bytes', 'fetch': fe, 'write': wr,
+        'total': fe + wr, 'algorithmic': algo, 'launches_profiled': n,
+        'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (scripts/pmc_traffic.sh, '
+                  'profiles/r01_pmc_hbm_traffic.csv); FETCH_SIZE doubled (gfx950 counts 128-B requests of 16-B/lane streams as 64 B), '
+                  'WRITE_SIZE as is; Infinity-Cache hits are included in FETCH_SIZE, so this is fabric (L2-miss) traffic, an upper '
+                  'bound on HBM bytes'}
+  json.dump(js, open(os.path.join(REPO, 'profiles', 'r01_halo_traffic.json'), 'w'), indent=1)
+  print(open(out).read()[:1500])
+  print(json.dumps(js, indent=1)[:600])
+
+
+if __name__ == '__main__':
+  main()
