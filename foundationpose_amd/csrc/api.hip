@@ -54,13 +54,13 @@ int fp_arena_ensure(fp_ctx *ctx, size_t bytes) {
   return FP_OK;
 }
 
-extern int g_halo_tail, g_halo_npw, g_halo_m16;
+extern int g_halo_tail, g_halo_npw, g_halo_form;
 
 extern "C" int fp_ctx_create(int device, fp_ctx **out) {
   FP_REQUIRE(out, "fp_ctx_create: null out");
   if (const char *e = getenv("FP_HALO_TAIL")) g_halo_tail = atoi(e) != 0;
   if (const char *e = getenv("FP_HALO_NPW")) g_halo_npw = atoi(e) == 2 ? 2 : 4;
-  if (const char *e = getenv("FP_HALO_MFMA")) g_halo_m16 = atoi(e) != 32;
+  if (const char *e = getenv("FP_HALO_FORM")) g_halo_form = atoi(e);
   int n = 0;
   FP_CHECK_HIP(hipGetDeviceCount(&n));
   FP_REQUIRE(device >= 0 && device < n, "fp_ctx_create: device %d out of range (%d visible)", device, n);

@@ -7,9 +7,9 @@
 //   * brings the input rows it needs ONCE into LDS (the "halo band") and feeds all 9 taps from it: a tap shift is just a
 //     different LDS address per lane (+-1 pixel, +-1 row; taps outside the image select a zero chunk),
 //   * streams the 3 taps of one kernel row of weights at a time (128 co x 32 ci x 3 = 24 KB, double buffered) by LDS-DMA.
-// Two forms live in this file (same results up to the last bits of the fp32 accumulation order):
-//   conv3x3_halo_d16_kernel  DEFAULT: 8 waves, 512 px, band by LDS-DMA (double buffered), v_mfma_f32_16x16x32_f16;
-//   conv3x3_halo_kernel      FP_HALO_MFMA=32: 4 or 8 waves, band through registers + ds_write, v_mfma_f32_32x32x16_f16
+// Two forms live in this file (v_mfma_f32_32x32x16_f16 both, identical results):
+//   conv3x3_halo_dma_kernel  DEFAULT: 8 waves, 512 px, band by LDS-DMA (double buffered);
+//   conv3x3_halo_kernel      FP_HALO_FORM=1: 4 or 8 waves (FP_HALO_NPW), band through registers + ds_write
 //                            (also carries the in-kernel cycle stamps of the diagnostic build, make -B EXTRA=-DHALO_STAMP).
 // Epilogue: accumulators start at the bias; residual (staged through LDS) + ReLU (+ positional embedding) in fp32, one
 // rounding to fp16, LDS transpose, 16-byte row-contiguous NHWC stores.
@@ -29,10 +29,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte reg
 // diagnostic build only (make STAMP=1): per-wave cycle sums of [wait + barrier] and [group body], see scripts/halo_stamps.py
 __device__ unsigned long long g_halo_stamps[4096 * 8 * 8];
 extern "C" int fp_dbg_halo_stamps(unsigned long long *host, int clear) {
-  if (host) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps));
+  if (host) (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps));
   if (clear) {
     static unsigned long long z[4096 * 8 * 8];
-    hipMemcpyToSymbol(HIP_SYMBOL(g_halo_stamps), z, sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_halo_stamps), z, sizeof(z));
   }
   return 0;
 }
@@ -391,22 +391,18 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
 
 // ------------------------------------------------------------------------------------------------------------------------
 // DEFAULT FORM.  8-wave tile (512 px x 128 co, one workgroup per CU) with the halo band staged by LDS-DMA as well, double
-// buffered, on v_mfma_f32_16x16x32_f16 (same FLOPs per LDS byte and per MFMA-pipe cycle as 32x32x16):
+// buffered:
 //   * halo pixels are 64 bytes, UNPADDED (so a DMA instruction's 64 lanes x 16 B land linearly: 16 pixels x 4 channel groups);
 //     bank conflicts are avoided by an XOR swizzle instead: pixel P keeps channel group c at position c ^ ((P >> 2) & 3),
-//     applied on the SOURCE address of the DMA (the destination of an LDS-DMA is always lane-linear);
+//     applied on the SOURCE address of the DMA (the destination of an LDS-DMA is always lane-linear).  A ds_read_b128 lane
+//     group ({0-3,12-15,20-27}, ...) then reads 16 pixels whose four members of each residue class mod 4 carry four
+//     different swizzle values, for any tile alignment and tap shift: conflict free;
 //   * no staging registers, no ds_write of the band, no barrier pair at the top of a chunk: the band of chunk cc+1 streams
 //     into the other buffer while chunk cc is multiplied, one DMA instruction per pixel-tile visit;
-//   * fragment geometry: lane r of a 16-pixel tile holds pixel PI2(r), with the pixels of
-//     lanes {0-3,12-15} in residues {0,1} mod 4 and those of lanes {4-11} in residues {2,3} - then the four pixels of one
-//     residue class inside a ds_read_b128 lane group always carry four different swizzle values, for any tile alignment;
-//     lane quarter q supplies channel group q; weight rows are swizzled by 2*((co>>3)&1).
+//   * v_mfma_f32_32x32x16_f16, a wave holds 64 co x 128 px (2 x 4 accumulator tiles); a kernel row is 24 "tile visits" of 2
+//     MFMAs, pixel fragments rotate through 4 registers, weight fragments of the next step go to a spare set.
+// (A 16x16x32 MFMA form of this tile was measured too: ~7 % more cycles at a ~8 % higher clock, the same time.)
 // ------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int halo_pi2(int r) {
-  const int k = (r < 4) ? r : (r < 12 ? r - 4 : r - 8);        // index 0..7 inside the lane's residue half
-  return (r >= 4 && r < 12) ? (k >> 1) * 4 + 2 + (k & 1) : (k >> 1) * 4 + (k & 1);
-}
-
 template <int W, int TM>
 struct HaloCfgD {
   static constexpr int MAXSLOT = (W - 1 + TM - 1) / W + 1 + 2;
@@ -423,33 +419,31 @@ struct HaloCfgD {
 };
 
 template <int W, int NT, bool RES, bool POST>
-__device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, const int c0, f16 *lds) {
+__device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, const int c0, f16 *lds) {
   constexpr int NPW = 4, TM = 32 * NT * NPW;
   using C = HaloCfgD<W, TM>;
   constexpr int H = W;
   constexpr int NTH = 128 * NPW;        // threads
   constexpr int PXW = 32 * NT;          // pixels per wave
-  constexpr int NJ = 2 * NT;            // 16-pixel tiles per wave
   constexpr int HQ = C::HQ;
   constexpr int WQ = 24 / (2 * NPW);    // weight DMA instructions per wave per group
   STAMP(const unsigned long long t_entry = __builtin_amdgcn_s_memtime(); const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();)
   f16 *wbuf = lds + C::WBUF_OFF;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NPW, wn = wave % NPW;
-  const int r16 = lane & 15, q4 = lane >> 4;
-  const int pr = halo_pi2(r16);
+  const int lr = lane & 31, lh = lane >> 5;
   const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by band row 0
   const int total_rows = p.Nimg * H;
   const int nchunk = p.Cin / HL_CK;
 
   // ---- B fragments: band index of the top-left tap of this lane's pixel in tile 0 (tile j, taps: see load_b) ----
-  const int pb = m0 + wn * PXW + pr - GR0 * W - W;
-  unsigned vmp[(NJ + 2) / 3];          // 9 validity bits (ky*3+kx) per pixel tile, three tiles per register
+  const int pb = m0 + wn * PXW + lr - GR0 * W - W;
+  unsigned vmp[(NT + 2) / 3];          // 9 validity bits (ky*3+kx) per 32-pixel tile, three tiles per register
 #pragma unroll
-  for (int t = 0; t < (NJ + 2) / 3; ++t) vmp[t] = 0;
+  for (int t = 0; t < (NT + 2) / 3; ++t) vmp[t] = 0;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int m = min(m0 + wn * PXW + j * 16 + pr, p.M - 1);
+  for (int j = 0; j < NT; ++j) {
+    const int m = min(m0 + wn * PXW + j * 32 + lr, p.M - 1);
     const int gr = m / W, ox = m - gr * W, oy = gr % H;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -459,8 +453,13 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) vmp[j / 3] |= 1u << ((j % 3) * 9 + ky * 3 + kx);
       }
   }
-  // ---- A fragments: row co = wm*64 + i*16 + r16 (i, tap: immediates); swizzle 2*((co>>3)&1) = 2*(r16>>3) for every i
-  const int wa = (wm * 64 + r16) * 32 + ((q4 ^ ((r16 >> 3) << 1)) * 8);
+  // ---- A fragments: row co = wm*64 + i*32 + lr, channel group ks*2 + lh at position ^ ((co>>2)&3) (same for co and co+32)
+  int wa[2];
+  {
+    const int co = wm * 64 + lr;
+    wa[0] = co * 32 + ((lh ^ ((co >> 2) & 3)) * 8);
+    wa[1] = co * 32 + (((2 + lh) ^ ((co >> 2) & 3)) * 8);
+  }
 
   // ---- halo band by LDS-DMA: instruction h of wave w lands band pixels (h*8 + w)*16 .. +15, lane i = (pixel i/4, position i%4)
   const int hpix_max = total_rows * W - 1;
@@ -474,8 +473,8 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
     const unsigned off = (unsigned)(gp * p.Cin + cc * HL_CK + c * 8) * 2u;
     glds16(p.in, off, lds + hb * C::HBUF_HALFS + (h * 8 + wave) * 512);
   };
-  // ---- weights (as in halo_tile) with this form's swizzle: row (g%8)*16 + lane/4 -> bit 3 of the row = (lane>>5)&1
-  const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ (((lane >> 5) & 1) << 1)) * 8)) * 2);
+  // ---- weights (as in halo_tile): row (g%8)*16 + lane/4 -> (row>>2)&3 = (lane>>4)&3
+  const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
   auto wstage = [&](int cc, int ky, int buf, auto q0c, auto q1c) __attribute__((always_inline)) {
     constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
 #pragma unroll
@@ -486,14 +485,21 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
     }
   };
 
-  // accumulators start at the bias: a lane owns channels wm*64 + i*16 + q4*4 + (0..3) of pixel PI2(r16) of each tile
-  floatx4 acc[4][NJ];
+  // accumulators start at the bias (fp32): a lane owns channels wm*64 + i*32 + rg*8 + lh*4 + (0..3) of its pixels
+  floatx16 acc[2][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 16 + q4 * 4);
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = floatx4{bv.x, bv.y, bv.z, bv.w};
-  }
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j][rg * 4 + 0] = bv.x;
+        acc[i][j][rg * 4 + 1] = bv.y;
+        acc[i][j][rg * 4 + 2] = bv.z;
+        acc[i][j][rg * 4 + 3] = bv.w;
+      }
+    }
 
   if (tid < 1) *reinterpret_cast<u32x4 *>(&lds[C::ZERO_OFF]) = u32x4{0, 0, 0, 0};
   {
@@ -534,71 +540,72 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
       }
       const bool more_w = ncc < nchunk, more_h = (ky == 0) && (cc + 1 < nchunk);
       const f16 *wb = wbuf + buf * C::WBUF_HALFS;
-      unsigned vm[(NJ + 2) / 3];           // keep the border selects inside the loop (see halo_tile)
+      unsigned vm[(NT + 2) / 3];           // keep the border selects inside the loop (see halo_tile)
 #pragma unroll
-      for (int t = 0; t < (NJ + 2) / 3; ++t) {
+      for (int t = 0; t < (NT + 2) / 3; ++t) {
         vm[t] = vmp[t];
         asm volatile("" : "+v"(vm[t]));
       }
-      // 3 steps (kx) x NJ pixel tiles = 3 NJ tile visits, 4 MFMAs each; pixel fragments rotate through BD registers (the
-      // fragment of visit t+BD is requested right after the MFMAs of visit t), weight fragments of step st+1 go to the spare
-      // set at the start of step st.  The tap's swizzle term is the same for all tiles of a step (tiles are 16 pixels apart).
-      constexpr int NV = 3 * NJ, BD = NJ < 4 ? NJ : 4;
-      half8 af[2][4], bf[BD];
-      int tapb[3];                         // half offset of (tap pixel, channel group q4) of tile 0, per kx
+      // 6 steps (kx, k-step) x NT pixel tiles = 6 NT tile visits, 2 MFMAs each; pixel fragments rotate through BD registers
+      // (the fragment of visit t+BD is requested right after the MFMAs of visit t), weight fragments of step st+1 go to the
+      // spare set at the start of step st.  A tap's swizzle term is the same for all tiles of a step (tiles are 32 px apart).
+      constexpr int NV = 6 * NT, BD = NT >= 4 ? 4 : 2;
+      half8 af[2][2], bf[BD];
+      int tapb[3][2];                      // half offset of (tap pixel, channel group ks*2 + lh) of tile 0
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int Pt = pb + ky * W + kx;
-        tapb[kx] = Pt * 32 + ((q4 ^ ((Pt >> 2) & 3)) * 8);
+        const int Pt = pb + ky * W + kx, sw = (Pt >> 2) & 3;
+        tapb[kx][0] = Pt * 32 + ((lh ^ sw) * 8);
+        tapb[kx][1] = Pt * 32 + (((2 + lh) ^ sw) * 8);
       }
-      auto load_a = [&](int kx, int set) __attribute__((always_inline)) {
+      auto load_a = [&](int st, int set) __attribute__((always_inline)) {
+        const int kx = st >> 1, ks = st & 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[set][i] = *reinterpret_cast<const half8 *>(&wb[wa + i * (16 * 32) + kx * (HL_BM * HL_CK)]);
+        for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const half8 *>(&wb[wa[ks] + i * (32 * 32) + kx * (HL_BM * HL_CK)]);
       };
       auto load_b = [&](auto tc) __attribute__((always_inline)) {
-        constexpr int t = decltype(tc)::value, kx = t / NJ, j = t % NJ;
-        constexpr int imm = j * 16 * 32;
+        constexpr int t = decltype(tc)::value, st = t / NT, j = t % NT, kx = st >> 1, ks = st & 1;
+        constexpr int imm = j * 32 * 32;
         const bool ok = (vm[j / 3] >> ((j % 3) * 9 + ky * 3 + kx)) & 1u;
-        const int base = ok ? tapb[kx] : (C::ZERO_OFF - (cc & 1) * C::HBUF_HALFS - imm);
+        const int base = ok ? tapb[kx][ks] : (C::ZERO_OFF - (cc & 1) * C::HBUF_HALFS - imm);
         bf[t % BD] = *reinterpret_cast<const half8 *>(&halo[base + imm]);
       };
       load_a(0, 0);
       load_b(IC<0>{});
-      if constexpr (BD > 1) load_b(IC<1>{});
+      load_b(IC<1>{});
       if constexpr (BD > 2) load_b(IC<2>{});
       if constexpr (BD > 3) load_b(IC<3>{});
       __builtin_amdgcn_sched_barrier(0);
       auto visit = [&](auto tc) __attribute__((always_inline)) {
-        constexpr int t = decltype(tc)::value, st = t / NJ, j = t % NJ, cur = st & 1;
-        if constexpr (j == 0 && st + 1 < 3) {
+        constexpr int t = decltype(tc)::value, st = t / NT, j = t % NT, cur = st & 1;
+        if constexpr (j == 0 && st + 1 < 6) {
           load_a(st + 1, cur ^ 1);
           __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cur][i], bf[t % BD], acc[i][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][0], bf[t % BD], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][1], bf[t % BD], acc[1][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (t + BD < NV) load_b(IC<t + BD>{});
-        // weight DMAs of the next group after the first visits; the next chunk's band DMAs after them, from visit NJ on
+        // weight DMAs of the next group in the first visits, the next chunk's band DMAs right after them
         // (program order "weights, then band": the counted vmcnt at ky=1 relies on it)
-        constexpr int DQ = (WQ + NJ - 1) / NJ, HV = (HQ + (NV - NJ) - 1) / (NV - NJ);
-        static_assert(HV == 1, "one band DMA per visit");
-        if constexpr (t * DQ < WQ) {
-          if (more_w) wstage(ncc, nky, buf ^ 1, IC<t * DQ>{}, IC<((t + 1) * DQ < WQ ? (t + 1) * DQ : WQ)>{});
-        } else if constexpr (t >= NJ && t - NJ < HQ) {
-          if (more_h) halo_dma(cc + 1, (cc + 1) & 1, IC<t - NJ>{});
+        static_assert(WQ + HQ <= NV, "DMA issue slots");
+        if constexpr (t < WQ) {
+          if (more_w) wstage(ncc, nky, buf ^ 1, IC<t>{}, IC<t + 1>{});
+        } else if constexpr (t - WQ < HQ) {
+          if (more_h) halo_dma(cc + 1, (cc + 1) & 1, IC<t - WQ>{});
         }
         __builtin_amdgcn_sched_barrier(0);
       };
 #define V4(a) visit(IC<(a) < NV ? (a) : NV - 1>{}); if constexpr ((a) + 1 < NV) visit(IC<(a) + 1 < NV ? (a) + 1 : NV - 1>{}); if constexpr ((a) + 2 < NV) visit(IC<(a) + 2 < NV ? (a) + 2 : NV - 1>{}); if constexpr ((a) + 3 < NV) visit(IC<(a) + 3 < NV ? (a) + 3 : NV - 1>{});
       V4(0) if constexpr (NV > 4) { V4(4) } if constexpr (NV > 8) { V4(8) V4(12) V4(16) V4(20) }
 #undef V4
-      static_assert(NV == 6 || NV == 24, "visit list covers NJ = 2 and NJ = 8");
+      static_assert(NV == 6 || NV == 24, "visit list covers NT = 1 and NT = 4");
       STAMP(t_body += __builtin_amdgcn_s_memtime() - tb;)
     }
   }
   STAMP(const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();)
 
-  // ---------------- epilogue (as in halo_tile; a lane holds 4 consecutive channels of ONE pixel per accumulator) ----------------
+  // ---------------- epilogue (as in halo_tile) ----------------
   f16 *stage = lds;   // [TM px][HL_SLD]
   constexpr int NRES = TM * 16 / NTH;
   u32x4 rv[NRES];
@@ -621,38 +628,47 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
     __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int pxl = wn * PXW + j * 16 + pr;
-    float4 pvs[4];
+  for (int j = 0; j < NT; ++j) {
+    const int pxl = wn * PXW + j * 32 + lr;
+    float4 pvs[2][4];
     if constexpr (POST) {
       const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pvs[i] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * 64 + i * 16 + q4 * 4);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
     }
-    half4 rq[4];
+    half4 rq[2][4];
     if constexpr (RES) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rq[i] = *reinterpret_cast<const half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 16 + q4 * 4]);
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) rq[i][rg] = *reinterpret_cast<const half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 32 + rg * 8 + lh * 4]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if constexpr (RES) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][e];
+      for (int rg = 0; rg < 4; ++rg) {
+        float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
+        if constexpr (RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][rg][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+        if constexpr (POST) {
+          const float4 pv = pvs[i][rg];
+          v[0] += pv.x;
+          v[1] += pv.y;
+          v[2] += pv.z;
+          v[3] += pv.w;
+        }
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
+        *reinterpret_cast<half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 32 + rg * 8 + lh * 4]) = hv;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
-      if constexpr (POST) {
-        v[0] += pvs[i].x;
-        v[1] += pvs[i].y;
-        v[2] += pvs[i].z;
-        v[3] += pvs[i].w;
-      }
-      half4 hv;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
-      *reinterpret_cast<half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 16 + q4 * 4]) = hv;
     }
   }
   __syncthreads();
@@ -685,19 +701,19 @@ __device__ __forceinline__ void halo_tile_d16(const ConvArgs &p, const int m0, c
 }
 
 template <int W, bool RES, bool POST>
-__global__ __launch_bounds__(512, 1) void conv3x3_halo_d16_kernel(ConvArgs p, int n_main) {
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, int n_main) {
   extern __shared__ __attribute__((aligned(16))) f16 lds[];
   constexpr int TMM = 512;
   const int n_ct = p.Cout / HL_BM;
   if ((int)blockIdx.x < n_main) {
     const int L = xcd_remap(blockIdx.x, n_main);
-    halo_tile_d16<W, 4, RES, POST>(p, (L / n_ct) * TMM, (L % n_ct) * HL_BM, lds);
+    halo_tile_dma<W, 4, RES, POST>(p, (L / n_ct) * TMM, (L % n_ct) * HL_BM, lds);
   } else {
     const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
     const int L = n_main + (t >> 2);
     const int m0 = (L / n_ct) * TMM + (t & 3) * (TMM / 4);
     if (m0 >= p.M) return;
-    halo_tile_d16<W, 1, RES, POST>(p, m0, (L % n_ct) * HL_BM, lds);
+    halo_tile_dma<W, 1, RES, POST>(p, m0, (L % n_ct) * HL_BM, lds);
   }
 }
 
@@ -773,7 +789,8 @@ static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
   return FP_OK;
 }
 
-int g_halo_m16 = 1;    // FP_HALO_MFMA=32 selects the 32x32x16 register-staged form (A/B timing; results differ in the last bits only)
+int g_halo_form = 0;   // FP_HALO_FORM: 0 = band by LDS-DMA, 8 waves (default); 1 = band through registers, FP_HALO_NPW x 2 waves
+                       // (A/B timing; identical results: same MFMA shape and accumulation order)
 
 template <int W, int NPW>
 static int launch_halo_flags(const ConvArgs &a, hipStream_t s) {
@@ -782,13 +799,13 @@ static int launch_halo_flags(const ConvArgs &a, hipStream_t s) {
 }
 
 template <int W, bool RES, bool POST>
-static int launch_halo_d16(const ConvArgs &a, hipStream_t s) {
+static int launch_halo_dma(const ConvArgs &a, hipStream_t s) {
   using C = HaloCfgD<W, 512>;
   static_assert(HaloCfgD<W, 128>::LDS_BYTES <= C::LDS_BYTES, "tail tiles fit the main tile's LDS");
   static bool attr_set = false;
   static int slots = 256;
   if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_d16_kernel<W, RES, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_dma_kernel<W, RES, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     int dev = 0;
     FP_CHECK_HIP(hipGetDevice(&dev));
     FP_CHECK_HIP(hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev));
@@ -797,19 +814,19 @@ static int launch_halo_d16(const ConvArgs &a, hipStream_t s) {
   const int n_tiles = ((a.M + 511) / 512) * (a.Cout / HL_BM);
   int n_main, n_tail4;
   halo_split(n_tiles, slots, &n_main, &n_tail4);
-  hipLaunchKernelGGL((conv3x3_halo_d16_kernel<W, RES, POST>), dim3(n_main + n_tail4), dim3(512), C::LDS_BYTES, s, a, n_main);
+  hipLaunchKernelGGL((conv3x3_halo_dma_kernel<W, RES, POST>), dim3(n_main + n_tail4), dim3(512), C::LDS_BYTES, s, a, n_main);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
 
 template <int W>
-static int launch_halo_d16_flags(const ConvArgs &a, hipStream_t s) {
-  if (a.post_add) return a.res ? launch_halo_d16<W, true, true>(a, s) : launch_halo_d16<W, false, true>(a, s);
-  return a.res ? launch_halo_d16<W, true, false>(a, s) : launch_halo_d16<W, false, false>(a, s);
+static int launch_halo_dma_flags(const ConvArgs &a, hipStream_t s) {
+  if (a.post_add) return a.res ? launch_halo_dma<W, true, true>(a, s) : launch_halo_dma<W, false, true>(a, s);
+  return a.res ? launch_halo_dma<W, true, false>(a, s) : launch_halo_dma<W, false, false>(a, s);
 }
 
 int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
-  if (g_halo_m16) return a.W == 40 ? launch_halo_d16_flags<40>(a, s) : launch_halo_d16_flags<20>(a, s);
+  if (g_halo_form == 0) return a.W == 40 ? launch_halo_dma_flags<40>(a, s) : launch_halo_dma_flags<20>(a, s);
   if (g_halo_npw == 2) return a.W == 40 ? launch_halo_flags<40, 2>(a, s) : launch_halo_flags<20, 2>(a, s);
   return a.W == 40 ? launch_halo_flags<40, 4>(a, s) : launch_halo_flags<20, 4>(a, s);
 }

@@ -26,9 +26,9 @@ def main():
     run(); torch.cuda.synchronize()
     buf = np.zeros((4096, 8, 8), dtype=np.uint64)
     L.fp_dbg_halo_stamps(buf.ctypes.data_as(ctypes.c_void_p), 0)
-    nw = 8 if int(os.environ.get('FP_HALO_NPW', '4')) == 4 else 4
+    nw = 4 if (os.environ.get('FP_HALO_FORM', '0') == '1' and os.environ.get('FP_HALO_NPW', '4') == '2') else 8
     if int(os.environ.get('FP_HALO_DBG', '0')) & 4:
-      b = buf[:200, :(8 if int(os.environ.get('FP_HALO_NPW', '4')) == 4 else 4)].reshape(-1, 8)
+      b = buf[:200, :(4 if (os.environ.get('FP_HALO_FORM', '0') == '1' and os.environ.get('FP_HALO_NPW', '4') == '2') else 8)].reshape(-1, 8)
       b = b[b[:, 7] > 0]
       f = lambda x: float(np.mean(x.astype(np.float64)))
       lo = np.uint64(0xffffffff)
