@@ -8,6 +8,7 @@ import logging
 import math
 import random
 
+import ctypes
 import numpy as np
 import torch
 
@@ -124,7 +125,17 @@ def bilateral_filter_depth(depth, radius=2, zfar=100, sigmaD=2, sigmaR=100000, d
 
 
 def depth2xyzmap(depth, K, uvs=None):
-  """src/Utils.py:399-417 (host numpy, float64 arithmetic, float32 result)."""
+  """src/Utils.py:399-417 (float64 arithmetic, float32 result).  numpy in -> numpy out on the host like the reference; a
+  device tensor in -> device tensor out through fp_depth2xyzmap_f64 (same arithmetic, no host copy)."""
+  if torch.is_tensor(depth) and depth.is_cuda:
+    if uvs is not None:
+      raise NotImplementedError('depth2xyzmap(uvs=...) on a device tensor')
+    d = depth.to(torch.float).contiguous()
+    ctx = _lib.Context.get(d.device)
+    out = torch.empty((d.shape[0], d.shape[1], 3), dtype=torch.float, device=d.device)
+    Kd, Kp = k_ptr(K)
+    check(lib().fp_depth2xyzmap_f64(ctx.handle, ptr(d), d.shape[0], d.shape[1], Kp, ptr(out), stream_ptr(d.device)))
+    return out
   invalid_mask = (depth < 0.001)
   H, W = depth.shape[:2]
   if uvs is None:
@@ -143,6 +154,21 @@ def depth2xyzmap(depth, K, uvs=None):
   xyz_map[vs, us] = pts
   xyz_map[invalid_mask] = 0
   return xyz_map
+
+
+def mask_depth_stats(depth, mask, min_depth=0.001):
+  """Reductions of guess_translation / register()'s validity test on the device (src/estimater.py:137-156,173-177):
+  dict(cmin, cmax, rmin, rmax, n_mask, n_usable, median) for a device depth image and a mask (anything non-zero = object)."""
+  d = torch.as_tensor(depth, dtype=torch.float, device='cuda').contiguous()
+  m = torch.as_tensor(np.ascontiguousarray(mask) if isinstance(mask, np.ndarray) else mask, device=d.device)
+  m = (m != 0).to(torch.uint8).contiguous()
+  assert m.shape == d.shape, 'mask and depth shapes differ'
+  ctx = _lib.Context.get(d.device)
+  st = (ctypes.c_int32 * 6)()
+  med = ctypes.c_float()
+  check(lib().fp_mask_depth_stats(ctx.handle, ptr(d), ptr(m), d.shape[0], d.shape[1], float(min_depth), st, ctypes.byref(med),
+                                  stream_ptr(d.device)))
+  return dict(cmin=st[0], cmax=st[1], rmin=st[2], rmax=st[3], n_mask=st[4], n_usable=st[5], median=np.float32(med.value))
 
 
 def depth2xyzmap_batch(depths, Ks, zfar):

@@ -1,5 +1,6 @@
 // extern "C" entry points of libfoundationpose_amd (see include/foundationpose_amd.h).
 #include "common.h"
+#include <cstring>
 
 #include <cmath>
 #include <cstdarg>
@@ -306,6 +307,30 @@ extern "C" int fp_bilateral_filter_depth(fp_ctx *ctx, const float *d_depth, int 
 extern "C" int fp_depth2xyzmap(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float zfar, float *d_xyz, void *stream) {
   FP_REQUIRE(ctx && d_depth && d_xyz && K && H > 0 && W > 0, "fp_depth2xyzmap: bad argument");
   return launch_depth2xyz(d_depth, H, W, K, zfar, d_xyz, (hipStream_t)stream);
+}
+
+extern "C" int fp_depth2xyzmap_f64(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float *d_xyz, void *stream) {
+  FP_REQUIRE(ctx && d_depth && d_xyz && K && H > 0 && W > 0, "fp_depth2xyzmap_f64: bad argument");
+  return launch_depth2xyz_f64(d_depth, H, W, K, d_xyz, (hipStream_t)stream);
+}
+
+extern "C" int fp_mask_depth_stats(fp_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int H, int W, float min_depth, int32_t *h_stats6,
+                                   float *h_median, void *stream) {
+  FP_REQUIRE(ctx && d_depth && d_mask && h_stats6 && h_median && H > 0 && W > 0, "fp_mask_depth_stats: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  FP_TRY(fp_arena_ensure(ctx, 4096));
+  const size_t mark = ctx->arena.off;
+  int *d_out = (int *)ctx->arena.take(8 * sizeof(int));
+  FP_REQUIRE(d_out, "fp_mask_depth_stats: arena exhausted");
+  int rc = launch_mask_depth_stats(d_depth, d_mask, H, W, min_depth, d_out, (float *)(d_out + 6), s);
+  ctx->arena.off = mark;
+  if (rc != FP_OK) return rc;
+  int host[8];
+  FP_CHECK_HIP(hipMemcpyAsync(host, d_out, sizeof(host), hipMemcpyDeviceToHost, s));
+  FP_CHECK_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < 6; ++i) h_stats6[i] = host[i];
+  memcpy(h_median, &host[6], sizeof(float));
+  return FP_OK;
 }
 
 extern "C" int fp_pose_update(fp_ctx *ctx, const float *d_poseA, const float *d_trans, const float *d_rot, int N, int rot_dim,

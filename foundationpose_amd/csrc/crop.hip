@@ -228,3 +228,95 @@ int launch_depth2xyz(const float *d, int H, int W, const double *K, float zfar, 
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
+
+// depth2xyzmap (src/Utils.py:399-417): the host function of the reference works in float64 (numpy promotes the float32 depth
+// against the float64 K) and rounds once to float32; depth < 0.001 -> 0.
+__global__ void depth2xyz_f64_kernel(const float *__restrict__ depth, int H, int W, double fx, double fy, double cx, double cy,
+                                     float *__restrict__ xyz) {
+  int w = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y * blockDim.y + threadIdx.y;
+  if (w >= W || h >= H) return;
+  const float z = depth[(size_t)h * W + w];
+  float o[3] = {0.f, 0.f, 0.f};
+  if (!(z < 0.001f)) {
+    o[0] = (float)__ddiv_rn(__dmul_rn(__dsub_rn((double)w, cx), (double)z), fx);
+    o[1] = (float)__ddiv_rn(__dmul_rn(__dsub_rn((double)h, cy), (double)z), fy);
+    o[2] = z;
+  }
+  size_t p = ((size_t)h * W + w) * 3;
+  xyz[p] = o[0];
+  xyz[p + 1] = o[1];
+  xyz[p + 2] = o[2];
+}
+
+// Statistics behind FoundationPose.guess_translation / the "valid too small" test of register() (src/estimater.py:137-156,
+// 173-177), one workgroup: bounding box of mask > 0, count of mask > 0, count of usable pixels (mask > 0 and depth >= min_depth)
+// and np.median of the usable depths (exact: bitwise radix select on the float pattern, two order statistics for an even
+// count, averaged in float32 like numpy's mean of the two middle float32 values).
+// out: [0] cmin [1] cmax [2] rmin [3] rmax [4] n_mask [5] n_usable, median
+__global__ __launch_bounds__(1024) void mask_depth_stats_kernel(const float *__restrict__ depth, const unsigned char *__restrict__ mask, int H,
+                                                                int W, float min_depth, int *__restrict__ out, float *__restrict__ median) {
+  __shared__ int s_red[6];
+  __shared__ unsigned s_cnt;
+  const int n = H * W, tid = threadIdx.x;
+  if (tid == 0) {
+    s_red[0] = 0x7fffffff; s_red[1] = -1; s_red[2] = 0x7fffffff; s_red[3] = -1; s_red[4] = 0; s_red[5] = 0;
+  }
+  __syncthreads();
+  int cmin = 0x7fffffff, cmax = -1, rmin = 0x7fffffff, rmax = -1, nm = 0, nu = 0;
+  for (int i = tid; i < n; i += blockDim.x) {
+    if (mask[i]) {
+      const int r = i / W, c = i - r * W;
+      cmin = min(cmin, c); cmax = max(cmax, c); rmin = min(rmin, r); rmax = max(rmax, r);
+      ++nm;
+      if (depth[i] >= min_depth) ++nu;
+    }
+  }
+  atomicMin(&s_red[0], cmin); atomicMax(&s_red[1], cmax); atomicMin(&s_red[2], rmin); atomicMax(&s_red[3], rmax);
+  atomicAdd(&s_red[4], nm); atomicAdd(&s_red[5], nu);
+  __syncthreads();
+  const int n_us = s_red[5];
+  if (tid < 6) out[tid] = s_red[tid];
+  if (n_us == 0) {
+    if (tid == 0) *median = 0.f;
+    return;
+  }
+  // usable depths are >= min_depth > 0: their bit patterns order like the values
+  float vals[2];
+  const int ranks[2] = {(n_us - 1) / 2, n_us / 2};
+  for (int k = 0; k < 2; ++k) {
+    unsigned prefix = 0, rank = (unsigned)ranks[k];
+    for (int b = 31; b >= 0; --b) {
+      __syncthreads();
+      if (tid == 0) s_cnt = 0;
+      __syncthreads();
+      unsigned c0 = 0;
+      const unsigned hi_mask = b == 31 ? 0u : (0xffffffffu << (b + 1));
+      for (int i = tid; i < n; i += blockDim.x) {
+        if (mask[i] && depth[i] >= min_depth) {
+          const unsigned u = __float_as_uint(depth[i]);
+          if ((u & hi_mask) == (prefix & hi_mask) && !((u >> b) & 1u)) ++c0;
+        }
+      }
+      atomicAdd(&s_cnt, c0);
+      __syncthreads();
+      const unsigned z = s_cnt;
+      if (rank >= z) {
+        rank -= z;
+        prefix |= 1u << b;
+      }
+    }
+    vals[k] = __uint_as_float(prefix);
+  }
+  if (tid == 0) *median = __fmul_rn(__fadd_rn(vals[0], vals[1]), 0.5f);
+}
+
+int launch_depth2xyz_f64(const float *d, int H, int W, const double *K, float *xyz, hipStream_t s) {
+  hipLaunchKernelGGL(depth2xyz_f64_kernel, grid2d(H, W), dim3(32, 8), 0, s, d, H, W, K[0], K[4], K[2], K[5], xyz);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+int launch_mask_depth_stats(const float *d, const unsigned char *mask, int H, int W, float min_depth, int *out6, float *median, hipStream_t s) {
+  hipLaunchKernelGGL(mask_depth_stats_kernel, dim3(1), dim3(1024), 0, s, d, mask, H, W, min_depth, out6, median);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}

@@ -108,8 +108,21 @@ class FoundationPose:
     logging.info(f"self.rot_grid: {self.rot_grid.shape}")
 
   # ------------------------------------------------------------------ hypotheses
-  def guess_translation(self, depth, mask, K):
-    """src/estimater.py:137-156: bounding-box centre of the mask back-projected at the median valid depth."""
+  def guess_translation(self, depth, mask, K, stats=None):
+    """src/estimater.py:137-156: bounding-box centre of the mask back-projected at the median valid depth.  With a device
+    depth image the reductions run on the device (`stats` = Utils.mask_depth_stats result; computed here when not given);
+    numpy inputs take the host path of the reference."""
+    if stats is None and torch.is_tensor(depth) and depth.is_cuda:
+      stats = U.mask_depth_stats(depth, mask, _MIN_DEPTH)
+    if stats is not None:
+      if stats['n_mask'] == 0:
+        logging.info('mask is all zero')
+        return np.zeros((3))
+      if stats['n_usable'] == 0:
+        logging.info("valid is empty")
+        return np.zeros((3))
+      pixel = np.asarray([(stats['cmin'] + stats['cmax']) / 2.0, (stats['rmin'] + stats['rmax']) / 2.0, 1.0]).reshape(3, 1)
+      return ((np.linalg.inv(K) @ pixel) * stats['median']).reshape(3)
     rows, cols = np.nonzero(mask > 0)
     if len(cols) == 0:
       logging.info('mask is all zero')
@@ -121,9 +134,9 @@ class FoundationPose:
     pixel = np.asarray([(cols.min() + cols.max()) / 2.0, (rows.min() + rows.max()) / 2.0, 1.0]).reshape(3, 1)
     return ((np.linalg.inv(K) @ pixel) * np.median(depth[usable])).reshape(3)
 
-  def generate_random_pose_hypo(self, K, rgb, depth, mask, scene_pts=None):
+  def generate_random_pose_hypo(self, K, rgb, depth, mask, scene_pts=None, stats=None):
     hyp = self.rot_grid.clone()
-    hyp[:, :3, 3] = torch.as_tensor(self.guess_translation(depth=depth, mask=mask, K=K), device='cuda', dtype=torch.float).reshape(1, 3)
+    hyp[:, :3, 3] = torch.as_tensor(self.guess_translation(depth=depth, mask=mask, K=K, stats=stats), device='cuda', dtype=torch.float).reshape(1, 3)
     return hyp
 
   def compute_add_err_to_gt_pose(self, poses):
@@ -146,15 +159,19 @@ class FoundationPose:
     U.set_seed(0)
     if self.glctx is None:
       self.glctx = U.RasterizeContext() if glctx is None else glctx
+    # the frame goes to the device once; filtering, the validity count, guess_translation's reductions and the
+    # back-projection all run there (the reference round-trips through numpy at each of these steps)
+    depth = torch.as_tensor(np.ascontiguousarray(depth), dtype=torch.float, device='cuda')
     depth = U.bilateral_filter_depth(U.erode_depth(depth, radius=2, device='cuda'), radius=2, device='cuda')
-    if ((depth >= _MIN_DEPTH) & (ob_mask > 0)).sum() < _MIN_VALID_PIXELS:
+    stats = U.mask_depth_stats(depth, ob_mask, _MIN_DEPTH)
+    if stats['n_usable'] < _MIN_VALID_PIXELS:
       logging.info('valid too small, return')
       fallback = np.eye(4)
-      fallback[:3, 3] = self.guess_translation(depth=depth, mask=ob_mask, K=K)
+      fallback[:3, 3] = self.guess_translation(depth=depth, mask=ob_mask, K=K, stats=stats)
       return fallback
     self.H, self.W = depth.shape[:2]
     self.K, self.ob_id, self.ob_mask = K, ob_id, ob_mask
-    hyp = self.generate_random_pose_hypo(K=K, rgb=rgb, depth=depth, mask=ob_mask)
+    hyp = self.generate_random_pose_hypo(K=K, rgb=rgb, depth=depth, mask=ob_mask, stats=stats)
     refined, scores = self._refine_and_score(K, rgb, depth, U.depth2xyzmap(depth, K), hyp, iteration)
     order = torch.as_tensor(scores).argsort(descending=True)
     self.poses, self.scores = refined[order], scores[order]

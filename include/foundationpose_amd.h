@@ -86,6 +86,14 @@ int fp_erode_depth(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, 
 int fp_bilateral_filter_depth(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float zfar, float sigmaD,
                               float sigmaR, float *d_out, void *stream);
 int fp_depth2xyzmap(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float zfar, float *d_xyz, void *stream);
+/* depth2xyzmap of the registration path (src/Utils.py:399-417): float64 arithmetic, one rounding to float32, depth < 0.001 -> 0. */
+int fp_depth2xyzmap_f64(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float *d_xyz, void *stream);
+/* The reductions behind FoundationPose.guess_translation and the "valid too small" test of register()
+ * (src/estimater.py:137-156,173-177) without a host copy of the depth image.  d_mask: H*W bytes, non-zero = object.
+ * h_stats6 (host): cmin, cmax, rmin, rmax of mask > 0 (cmax = -1 if the mask is empty), count of mask > 0, count of usable
+ * pixels (mask > 0 and depth >= min_depth); h_median (host): np.median of the usable depths (0 if none).  Synchronises. */
+int fp_mask_depth_stats(fp_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int H, int W, float min_depth, int32_t *h_stats6,
+                        float *h_median, void *stream);
 
 /* ---- networks -------------------------------------------------------------------------------- */
 typedef struct {

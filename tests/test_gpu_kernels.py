@@ -283,3 +283,40 @@ def test_attention_vs_reference(fp):
   ref = (torch.softmax(q @ k.transpose(-1, -2) / 128 ** 0.5, -1) @ vv).transpose(1, 2).reshape(B * T, 512)
   err = float((out.float().cpu() - ref).abs().max())
   assert err <= 2e-3, err
+
+
+def test_register_prelude_on_device(sc, fp, golden):
+  """back-projection and guess_translation's reductions without a host copy of the depth image.
+  Pinned by the REFERENCE's own outputs (tests/golden: depth2xyzmap, FoundationPose.guess_translation run unmodified)."""
+  from foundationpose_amd import Utils as U
+  from foundationpose_amd.estimater import FoundationPose
+  from oracle import geometry as G
+  K = sc['K']
+  # (1) golden inputs of the reference (12 x 16 image with 20 % dropout, rectangular mask)
+  depth, mask = golden['d2x_depth'], golden['gt_mask']
+  d_dev = torch.from_numpy(depth).cuda()
+  xyz = U.depth2xyzmap(d_dev, K)
+  assert xyz.is_cuda and np.array_equal(xyz.cpu().numpy(), golden['d2x_xyz'])            # bit-exact (float64 math, one rounding)
+  dummy = type('E', (), {})()
+  t = FoundationPose.guess_translation(dummy, depth=d_dev, mask=mask, K=K)
+  np.testing.assert_allclose(t, golden['gt_center'], rtol=0, atol=1e-12)
+  t0 = FoundationPose.guess_translation(dummy, depth=d_dev, mask=np.zeros_like(mask), K=K)
+  assert np.array_equal(t0, golden['gt_center_empty'])
+  # (2) full frame: every statistic against numpy, odd and even counts of usable pixels (median = mean of two middles)
+  dfull = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+  for drop in (0, 1):
+    m = sc['mask'].copy()
+    if drop:
+      r, c = np.argwhere(m & (dfull >= 0.001))[0]
+      m[r, c] = False
+    st = U.mask_depth_stats(torch.from_numpy(dfull).cuda(), m)
+    rows, cols = np.nonzero(m)
+    usable = m & (dfull >= 0.001)
+    assert (st['cmin'], st['cmax'], st['rmin'], st['rmax']) == (cols.min(), cols.max(), rows.min(), rows.max())
+    assert st['n_mask'] == m.sum() and st['n_usable'] == usable.sum()
+    assert st['median'] == np.median(dfull[usable])                                        # exact
+  np.testing.assert_array_equal(U.depth2xyzmap(torch.from_numpy(dfull).cuda(), K).cpu().numpy(), G.depth2xyzmap(dfull, K))
+  # (3) no usable pixel: mask entirely on dropped depth
+  z = np.zeros_like(dfull)
+  st = U.mask_depth_stats(torch.from_numpy(z).cuda(), sc['mask'])
+  assert st['n_usable'] == 0 and st['n_mask'] == sc['mask'].sum() and st['median'] == 0
