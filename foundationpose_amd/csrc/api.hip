@@ -88,6 +88,13 @@ extern "C" int fp_ctx_destroy(fp_ctx *ctx) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  if (ctx->side_ready) {
+    for (int i = 0; i < fp_ctx::NSIDE; ++i) {
+      (void)hipStreamDestroy(ctx->side[i]);
+      (void)hipEventDestroy(ctx->ev_join[i]);
+    }
+    (void)hipEventDestroy(ctx->ev_fork);
+  }
   if (ctx->arena.base) (void)hipFree(ctx->arena.base);
   if (ctx->zero_page) (void)hipFree(ctx->zero_page);
   delete ctx;
@@ -362,6 +369,56 @@ static int check_objs(const fp_object_batch *objs, int n_obj, int *total) {
   return FP_OK;
 }
 
+// Fork / join of the per-object stages of a multi-object pass onto the context's side streams (single object: everything
+// stays on the launch stream).
+struct ObjectFanout {
+  fp_ctx *ctx;
+  hipStream_t main;
+  bool fan;
+  bool used[fp_ctx::NSIDE] = {};
+  int rc = FP_OK;
+  ObjectFanout(fp_ctx *c, hipStream_t s, int n_active) : ctx(c), main(s), fan(n_active > 1) {
+    if (!fan) return;
+    if (!ctx->side_ready) {
+      bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; ok && i < fp_ctx::NSIDE; ++i)
+        ok = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        fan = false;          // no side streams: run the objects one after the other
+        return;
+      }
+      ctx->side_ready = true;
+    }
+    if (hipEventRecord(ctx->ev_fork, main) != hipSuccess) fan = false;
+  }
+  hipStream_t stream_for(int k) {
+    if (!fan) return main;
+    const int i = k % fp_ctx::NSIDE;
+    if (!used[i]) {
+      used[i] = true;
+      if (hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0) != hipSuccess) rc = FP_EHIP;
+    }
+    return ctx->side[i];
+  }
+  int join() {
+    if (fan)
+      for (int i = 0; i < fp_ctx::NSIDE; ++i)
+        if (used[i]) {
+          if (hipEventRecord(ctx->ev_join[i], ctx->side[i]) != hipSuccess || hipStreamWaitEvent(main, ctx->ev_join[i], 0) != hipSuccess) rc = FP_EHIP;
+          used[i] = false;
+        }
+    if (rc != FP_OK) fp_set_error("multi-object pass: stream fork/join failed");
+    return rc;
+  }
+};
+
+static int count_active(const fp_object_batch *objs, int n_obj) {
+  int k = 0;
+  for (int o = 0; o < n_obj; ++o) k += objs[o].n > 0;
+  return k;
+}
+
 extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
                                        float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream) {
   FP_REQUIRE(ctx && net && cfg && d_poses, "fp_refine_predict_multi: null argument");
@@ -382,19 +439,23 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
     TAKE(pose_tmp, float, (size_t)N * 16);
     TAKE(net_in, f16, (size_t)2 * N * img);
     float *tr = d_trans ? d_trans : trans, *ro = d_rot ? d_rot : rot;
+    const int n_active = count_active(objs, n_obj);
     for (int it = 0; it < iteration; ++it) {
-      int off = 0;
+      int off = 0, k = 0;
+      ObjectFanout fo(ctx, s, n_active);
       for (int o = 0; o < n_obj; ++o) {       // per-object: crop window, render (side A), observed crop (side B)
         const fp_object_batch &ob = objs[o];
         if (ob.n == 0) continue;
+        hipStream_t so = fo.stream_for(k++);
         float *p = d_poses + (size_t)off * 16;
-        FP_TRY(launch_crop_window_tf(p, ob.n, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, s));
+        FP_TRY(launch_crop_window_tf(p, ob.n, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
         FP_TRY(fp_render_net(ctx, ob.mesh, p, ob.n, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
-                             cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, s));
+                             cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, so));
         FP_TRY(fp_crop_observed(ctx, ob.d_rgb, ob.d_geom, ob.H, ob.W, ob.K, tf + (size_t)off * 9, p, ob.n, 160, 160, 0, ob.mesh_diameter,
-                                cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, s));
+                                cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, so));
         off += ob.n;
       }
+      FP_TRY(fo.join());
       FP_TRY(fp_refine_forward(ctx, net, net_in, N, tr, ro, s));     // ONE network pass for every object
       off = 0;
       for (int o = 0; o < n_obj; ++o) {
@@ -437,18 +498,21 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
     TAKE(tf, float, (size_t)N * 9);
     TAKE(bbox, float, (size_t)N * 4);
     TAKE(net_in, f16, (size_t)2 * N * img);
-    int off = 0;
+    int off = 0, k = 0;
+    ObjectFanout fo(ctx, s, count_active(objs, n_obj));
     for (int o = 0; o < n_obj; ++o) {
       const fp_object_batch &ob = objs[o];
       if (ob.n == 0) continue;
+      hipStream_t so = fo.stream_for(k++);
       const float *p = d_poses + (size_t)off * 16;
-      FP_TRY(launch_crop_window_tf(p, ob.n, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, s));
+      FP_TRY(launch_crop_window_tf(p, ob.n, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
       FP_TRY(fp_render_net(ctx, ob.mesh, p, ob.n, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
-                           net_in + (size_t)off * img, s));
+                           net_in + (size_t)off * img, so));
       FP_TRY(fp_crop_observed(ctx, ob.d_rgb, ob.d_geom, ob.H, ob.W, ob.K, tf + (size_t)off * 9, p, ob.n, 160, 160, 1, ob.mesh_diameter,
-                              normalize_xyz, 1, net_in + ((size_t)N + off) * img, s));
+                              normalize_xyz, 1, net_in + ((size_t)N + off) * img, so));
       off += ob.n;
     }
+    FP_TRY(fo.join());
     FP_TRY(fp_score_features(ctx, net, net_in, N, d_feats, s));
     return FP_OK;
   };

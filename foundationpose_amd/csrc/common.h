@@ -84,6 +84,13 @@ struct fp_ctx {
   std::vector<PendingEvent> pending;
   int num_cu = 256;
   void *zero_page = nullptr;   // 4 KB of zeros: DMA source for out-of-image taps
+  // side streams for the per-object stages (crop window, render, observed crop) of a multi-object pass: with 8 objects
+  // x 32 hypotheses a render launch fills a quarter of the chip, so the objects' stages run side by side and join the
+  // launch stream before the (single) network pass
+  static constexpr int NSIDE = 8;
+  hipStream_t side[NSIDE] = {};
+  hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {};
+  bool side_ready = false;
 };
 
 int fp_arena_ensure(fp_ctx *ctx, size_t bytes);

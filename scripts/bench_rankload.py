@@ -1,0 +1,35 @@
+"""Per-rank GPU work of `bench.py --gpus W`, emulated on ONE GPU without a process group: W objects, this rank's
+ceil(252/W)-hypothesis slice of each through predict_multi / extract_features_multi (the all-gather and the 0.66-GFLOP
+tail are left out).  Weak scaling holds if the time does not grow with W.    usage: python scripts/bench_rankload.py 1 2 4 8"""
+import math, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+
+def main():
+  device = torch.device('cuda', 0)
+  worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+  est, objects_all = bench.build_job(device, n_objects=max(worlds), rank=0)
+  est.refiner.ctx.reserve(bench.N_HYP + 8)
+  for W in worlds:
+    objects = objects_all[:W]
+    n = math.ceil(bench.N_HYP / W)
+
+    def step():
+      refined = est.refiner.predict_multi([dict(rgb=ob['rgb'], xyz_map=ob['xyz'], K=ob['K'], mesh_tensors=est.mesh_tensors,
+                                                mesh_diameter=est.diameter, ob_in_cams=ob['poses'][:n]) for ob in objects], iteration=bench.ITER)
+      return est.scorer.extract_features_multi([dict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], mesh_tensors=est.mesh_tensors,
+                                                     mesh_diameter=est.diameter, ob_in_cams=refined[o * n:(o + 1) * n])
+                                                for o, ob in enumerate(objects)])
+    step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+      step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print(f'world {W}: {W} objects x {n} hypotheses on this rank: {dt * 1e3:.2f} ms/step  ({W * n / dt:.0f} hyp/s per GPU)')
+
+
+if __name__ == '__main__':
+  main()
