@@ -457,15 +457,18 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
       }
       FP_TRY(fo.join());
       FP_TRY(fp_refine_forward(ctx, net, net_in, N, tr, ro, s));     // ONE network pass for every object
+      // pose update: one launch per run of objects with the same translation scale (one launch when they share a mesh)
       off = 0;
-      for (int o = 0; o < n_obj; ++o) {
-        const fp_object_batch &ob = objs[o];
-        if (ob.n == 0) continue;
-        const float trans_scale = cfg->normalize_xyz ? (float)(ob.mesh_diameter / 2) : 1.f;
-        FP_TRY(launch_pose_update(d_poses + (size_t)off * 16, tr + (size_t)off * 3, ro + (size_t)off * rot_dim, ob.n, rot_dim,
-                                  cfg->trans_rep_tanh, cfg->trans_normalizer[0], cfg->trans_normalizer[1], cfg->trans_normalizer[2],
-                                  cfg->rot_normalizer, trans_scale, pose_tmp + (size_t)off * 16, s));
-        off += ob.n;
+      for (int o = 0; o < n_obj;) {
+        const float trans_scale = cfg->normalize_xyz ? (float)(objs[o].mesh_diameter / 2) : 1.f;
+        int cnt = 0, e = o;
+        while (e < n_obj && (cfg->normalize_xyz ? (float)(objs[e].mesh_diameter / 2) : 1.f) == trans_scale) cnt += objs[e++].n;
+        if (cnt > 0)
+          FP_TRY(launch_pose_update(d_poses + (size_t)off * 16, tr + (size_t)off * 3, ro + (size_t)off * rot_dim, cnt, rot_dim,
+                                    cfg->trans_rep_tanh, cfg->trans_normalizer[0], cfg->trans_normalizer[1], cfg->trans_normalizer[2],
+                                    cfg->rot_normalizer, trans_scale, pose_tmp + (size_t)off * 16, s));
+        off += cnt;
+        o = e;
       }
       FP_CHECK_HIP(hipMemcpyAsync(d_poses, pose_tmp, (size_t)N * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
