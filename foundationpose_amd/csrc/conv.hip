@@ -75,10 +75,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     wsrc[q] = p.w + (size_t)(c0 + co) * p.Kpad + ((chp ^ ((co >> 2) & 3)) * 8);
   }
   // DMA instruction d of a stage: d = 0..3 the activation gather (pixel group d), d = 4.. the weights
+  // 1x1 (Linear) layers: a pixel's K-row is contiguous, the gather address of step kt is a fixed per-lane base + kt*64 B
+  // (pixels past M read the zero page with stride 0) - no per-step tap / bounds arithmetic in front of the DMA
+  const f16 *xlin[4];
+  int xlin_step[4];
+  const bool lin = KW == 1 && !CIN8 && p.stride == 1 && p.pad == 0;     // output pixel m reads input pixel m
+  if (lin) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m0 + (q * 4 + wave) * 16 + (lane >> 2);
+      const bool mv = m < p.M;
+      xlin[q] = mv ? p.in + (size_t)m * p.Cin + xch[q] * 8 : zero_page;
+      xlin_step[q] = mv ? C2_BK : 0;
+    }
+  }
   auto stage_one = [&](int kt, int buf, int d) __attribute__((always_inline)) {
     f16 *xs = smem + buf * (XH + WH), *ws = xs + XH;
     if (d < 4) {
       const int q = d;
+      if (lin) {
+        glds16c(xlin[q] + kt * xlin_step[q], xs + (q * 4 + wave) * 512);
+        return;
+      }
       const int k = kt * C2_BK + xch[q] * 8;
       int tap, ci;
       if (CIN8) {
