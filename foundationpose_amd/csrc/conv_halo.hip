@@ -826,6 +826,8 @@ static int launch_halo_dma_flags(const ConvArgs &a, hipStream_t s) {
 }
 
 int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
+  // lane offsets into the input tensor are 32-bit byte offsets from its base
+  FP_REQUIRE((double)a.M * a.Cin * 2.0 < 4294967296.0, "conv3x3: input tensor of %.1f GB exceeds the 4 GB the kernel addresses", (double)a.M * a.Cin * 2e-9);
   if (g_halo_form == 0) return a.W == 40 ? launch_halo_dma_flags<40>(a, s) : launch_halo_dma_flags<20>(a, s);
   if (g_halo_npw == 2) return a.W == 40 ? launch_halo_flags<40, 2>(a, s) : launch_halo_flags<20, 2>(a, s);
   return a.W == 40 ? launch_halo_flags<40, 4>(a, s) : launch_halo_flags<20, 4>(a, s);

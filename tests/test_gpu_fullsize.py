@@ -165,3 +165,25 @@ def test_multi_object_pass_equals_per_object_passes(env):
   empty = dict(objs[0], ob_in_cams=env['poses'][:0])
   r2 = refiner.predict_multi([empty, objs[1]], iteration=1)
   assert r2.shape == (152, 4, 4)
+
+
+def test_four_objects_in_one_network_pass_1008(env):
+  """configs[3] at full size in ONE pass: RefineNet and the ScoreNet feature extractor on 4 x 252 = 1008 hypotheses
+  (2016 input images, 51.6 M stem pixels: the largest tensors the 32-bit lane offsets of the kernels see) must equal four
+  252-hypothesis passes bit for bit."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  r, sc = env['refiner'], env['scorer']
+  n4 = 4 * N
+  r.ctx.reserve(n4)
+  x = _net_inputs(n4, 17)
+  t_all, r_all = _refine(env, x, n4)
+  feats = torch.empty((n4, 512), device='cuda')
+  check(lib().fp_score_features(sc.ctx.handle, sc.model.handle, ptr(x), n4, ptr(feats), stream_ptr()))
+  assert torch.isfinite(t_all).all() and torch.isfinite(feats).all()
+  for o in range(4):
+    part = torch.cat([x[o * N:(o + 1) * N], x[n4 + o * N:n4 + (o + 1) * N]], 0).contiguous()
+    t_p, r_p = _refine(env, part, N)
+    assert torch.equal(t_p, t_all[o * N:(o + 1) * N]) and torch.equal(r_p, r_all[o * N:(o + 1) * N])
+    f_p = torch.empty((N, 512), device='cuda')
+    check(lib().fp_score_features(sc.ctx.handle, sc.model.handle, ptr(part), N, ptr(f_p), stream_ptr()))
+    assert torch.equal(f_p, feats[o * N:(o + 1) * N])

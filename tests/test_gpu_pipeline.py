@@ -240,3 +240,38 @@ def test_readme_pipeline_protocol_end_to_end(estimators):
   pipe.processors[0] = Frame(False)
   out2 = pipe.run(PipelineData())
   assert not out2.errors and np.abs(out2.pose - out.pose).max() < 0.1
+
+
+def test_other_frame_size_and_intrinsics(estimators):
+  """Nothing in the path is tied to 480x640 / the YCB intrinsics: a 360x500 frame (odd strides for every 16-byte access),
+  a camera with other focal lengths and an off-centre principal point, object near the image border.  4 hypotheses,
+  2 refinement iterations + scoring against the oracle, same tolerances as config[0]."""
+  from foundationpose_amd import synthetic as S
+  from oracle import geometry as G
+  from oracle import predict as OP
+  from oracle.render import nvdiffrast_render as oracle_render
+  sc0, est, orc = estimators['sc'], estimators['est'], estimators['orc']
+  H, W = 360, 500
+  K = np.array([[610.0, 0, 231.5], [0, 595.0, 171.25], [0, 0, 1]])
+
+  def rf(K_, H_, W_, pose):
+    c, d, _ = oracle_render(K=K_, H=H_, W=W_, ob_in_cams=pose, mesh_tensors=sc0['mt'], use_light=True)
+    return c[0].numpy(), d[0].numpy()
+  sc = S.make_scene(rf, sc0['mt'], seed=5, H=H, W=W, K=K, t=(-0.16, 0.09, 0.62))       # partly cut by the left border
+  assert sc['mask'].any() and sc['mask'][:, 0].any()
+  depth = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+  xyz_map = G.depth2xyzmap(depth, K)
+  poses0 = sc0['grid'][[0, 7, 100, 251]].copy()
+  poses0[:, :3, 3] = G.guess_translation(depth, sc['mask'], K).astype(np.float32)
+  pg, _ = est.refiner.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=sc['rgb'], depth=depth, K=K, ob_in_cams=poses0,
+                              xyz_map=xyz_map, mesh_diameter=est.diameter, iteration=2)
+  po = OP.refine_predict(orc.refine_cfg, orc.refine_sd, sc['rgb'], depth, K, poses0, xyz_map, sc0['mt'], sc0['diameter'], iteration=2, chunk=4)
+  assert float((pg.cpu() - po).abs().max()) < 1e-3
+  sg, _ = est.scorer.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=sc['rgb'], depth=depth, K=K, ob_in_cams=po.numpy(),
+                             mesh_diameter=est.diameter)
+  so = OP.score_predict(orc.score_cfg, orc.score_sd, sc['rgb'], depth, K, po.numpy(), sc0['mt'], sc0['diameter'], chunk=4)
+  sg, so = sg.cpu().numpy(), so.numpy()
+  assert np.abs((sg - sg.mean()) - (so - so.mean())).max() < 0.25 * max(float(so.std()), 1e-4) and abs(float((sg - so).mean())) < 5e-3
+  # the integrated call on this frame (device prelude: filtering, stats, float64 back-projection)
+  pose = est.register(K=K, rgb=sc['rgb'], depth=sc['depth'], ob_mask=sc['mask'], iteration=1)
+  assert pose.shape == (4, 4) and np.isfinite(pose).all()
