@@ -157,8 +157,7 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
     constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
 #pragma unroll
     for (int q = Q0; q < Q1; ++q) {
-      constexpr int dummy_npw = NPW;
-      const int g0 = q * 2 * dummy_npw;      // piece index without the wave part (wave < 2 NPW <= 8 never carries into g/8)
+      const int g0 = q * 2 * NPW;            // piece index without the wave part (wave < 2 NPW <= 8 never carries into g/8)
       const f16 *sb = p.w + (size_t)(c0 + (g0 & 7) * 16) * p.Kpad + (ky * 3 + (g0 >> 3)) * p.Cin + cc * HL_CK;
       glds16(sb, woff, wbuf + buf * C::WBUF_HALFS + (q * 2 * NWN + wave) * 512);
     }
@@ -220,7 +219,8 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
         nky = 0;
         ncc = cc + 1;
       }
-      const bool more_w = ncc < nchunk && !(dbg & 2), more_h = (ky == 0) && (cc + 1 < nchunk) && !(dbg & 1);
+      // (diagnostic build only: dbg bit 0 / 1 switch the halo / weight reloads off - wrong results, timing experiments)
+      const bool more_w = ncc < nchunk STAMP(&& !(dbg & 2)), more_h = (ky == 0) && (cc + 1 < nchunk) STAMP(&& !(dbg & 1));
       const f16 *wb = wbuf + buf * C::WBUF_HALFS;
       // keep the per-tap border selects INSIDE the loop: hoisted, their 72 results would not fit the register file
       unsigned vm[NT];
@@ -772,7 +772,11 @@ static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
   using C = HaloCfg<W, TMM>;
   static bool attr_set = false;
   static int slots = 512;
-  static int dbg = getenv("FP_HALO_DBG") ? atoi(getenv("FP_HALO_DBG")) : 0;   // experiment: 1 = no halo reloads, 2 = no weight reloads (wrong results)
+#ifdef HALO_STAMP
+  static int dbg = getenv("FP_HALO_DBG") ? atoi(getenv("FP_HALO_DBG")) : 0;   // diagnostic build: 1 = no halo reloads, 2 = no weight reloads, 4 = epilogue stamps
+#else
+  const int dbg = 0;
+#endif
   if (!attr_set) {
     FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W, NPW, RES, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     int dev = 0, cus = 256;
