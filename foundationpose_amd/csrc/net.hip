@@ -35,7 +35,7 @@ struct fp_net {
   std::vector<void *> allocs;
 };
 
-// Hypotheses per network pass.  FP_CHUNK=n overrides; 0 = whole batch.
+// Hypotheses per network pass: the whole batch.  FP_CHUNK=n (environment, experiments only) splits it.
 static int fp_hyp_chunk(int n_total) {
   static int env = getenv("FP_CHUNK") ? atoi(getenv("FP_CHUNK")) : -1;
   int ch = env >= 0 ? env : 0;
@@ -405,8 +405,8 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     }
     return FP_OK;
   };
-  // hypothesis chunks reuse the SAME arena addresses: a chunk's activations (<= ~0.9 GB at 72 hypotheses... sized by
-  // fp_hyp_chunk so that producer->consumer tensors stay resident in the 256 MiB Infinity Cache
+  // hypothesis chunks (FP_CHUNK, default: the whole batch in one pass) reuse the SAME arena addresses.  Chunking to keep
+  // producer -> consumer tensors inside the 256 MiB Infinity Cache was measured and is slower (smaller grids, same traffic)
   int rc = FP_OK;
   for (int s0 = 0; s0 < NT && rc == FP_OK; s0 += CH) {
     rc = body(s0, std::min(CH, NT - s0));
