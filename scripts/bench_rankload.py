@@ -24,11 +24,22 @@ def main():
                                                 for o, ob in enumerate(objects)])
     step(); torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host = 0.0
     for _ in range(3):
+      h0 = time.perf_counter()
       step()
+      host += time.perf_counter() - h0          # time the host needs to ENQUEUE a step (the calls are asynchronous)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print(f'world {W}: {W} objects x {n} hypotheses on this rank: {dt * 1e3:.2f} ms/step  ({W * n / dt:.0f} hyp/s per GPU)')
+    ctx = est.refiner.ctx
+    ctx.prof_reset(); ctx.prof_enable(True)
+    step(); torch.cuda.synchronize()
+    ctx.prof_enable(False)
+    cls = {c: ctx.prof_read(c) for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'render')}
+    print('   per-class ms (HIP events; overlapping launches on side streams each count their own span): '
+          + '  '.join(f"{c} {v['total_ms']:.2f}/{v['launches']}" for c, v in cls.items()))
+    print(f'world {W}: {W} objects x {n} hypotheses on this rank: {dt * 1e3:.2f} ms/step  ({W * n / dt:.0f} hyp/s per GPU; '
+          f'host enqueue {host / 3 * 1e3:.2f} ms/step)')
 
 
 if __name__ == '__main__':
