@@ -66,17 +66,23 @@ def build_job(device, n_objects, rank):
 def step(est, objects, world, rank):
   """One register-core pass over all objects; returns per-object (best index, best pose) finalised on
   the owning rank (object o is finalised by rank o % world)."""
-  from foundationpose_amd.dist import all_gather_rows, pack_rows, shard_ranges, unpack_rows
+  from foundationpose_amd.dist import all_gather_rows, gather_order, pack_rows, rotated_shard, shard_ranges, unpack_rows
   shard = math.ceil(N_HYP / world)
-  a, b = shard_ranges(N_HYP, world)[rank]
-  # this rank's slice of EVERY object goes through the networks as one batch (render / crop stay per object)
+  ranges = shard_ranges(N_HYP, world)
+  # this rank's shard of EVERY object goes through the networks as one batch (render / crop stay per object); the shard
+  # index is rotated by the object index so that the short last shard (252 = 7 x 32 + 28) lands on a different rank for
+  # every object: each rank of an 8-GPU job handles exactly 252 hypotheses
+  sl = [ranges[rotated_shard(o, rank, world)] for o in range(len(objects))]
   refined = est.refiner.predict_multi([dict(rgb=ob['rgb'], xyz_map=ob['xyz'], K=ob['K'], mesh_tensors=est.mesh_tensors,
-                                            mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b]) for ob in objects], iteration=ITER)
-  n = b - a
+                                            mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b])
+                                       for ob, (a, b) in zip(objects, sl)], iteration=ITER)
+  offs = [0]
+  for a, b in sl:
+    offs.append(offs[-1] + (b - a))
   feats = est.scorer.extract_features_multi([dict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], mesh_tensors=est.mesh_tensors,
-                                                  mesh_diameter=est.diameter, ob_in_cams=refined[o * n:(o + 1) * n])
+                                                  mesh_diameter=est.diameter, ob_in_cams=refined[offs[o]:offs[o + 1]])
                                              for o, ob in enumerate(objects)])
-  blocks = [(feats[o * n:(o + 1) * n], refined[o * n:(o + 1) * n]) for o in range(len(objects))]
+  blocks = [(feats[offs[o]:offs[o + 1]], refined[offs[o]:offs[o + 1]]) for o in range(len(objects))]
   results = {}
   if world > 1:
     rows = torch.cat([pack_rows(f, p, shard) for f, p in blocks], 0)          # (O*shard, 528)
@@ -85,7 +91,7 @@ def step(est, objects, world, rank):
     if o % world != rank:
       continue
     if world > 1:
-      feats_all, poses_all = unpack_rows(gathered[:, o].reshape(world * shard, -1), N_HYP, world)
+      feats_all, poses_all = unpack_rows(gathered[gather_order(o, world), o].reshape(world * shard, -1), N_HYP, world)
     else:
       feats_all, poses_all = blocks[o]
     logits, am = est.scorer.score_tail(feats_all, L=N_HYP)

@@ -413,9 +413,21 @@ struct ObjectFanout {
   }
 };
 
-static int count_active(const fp_object_batch *objs, int n_obj) {
+// Objects whose crop windows and renders can share one launch: same mesh, camera and frame size (their hypotheses are
+// contiguous in d_poses).  A rank of the sharded multi-GPU job holds a slice of several objects of ONE mesh: one 252-hypothesis
+// render instead of eight 32-hypothesis ones that each fill a quarter of the chip.
+static bool same_render_key(const fp_object_batch &a, const fp_object_batch &b) {
+  return a.mesh == b.mesh && a.H == b.H && a.W == b.W && a.mesh_diameter == b.mesh_diameter && memcmp(a.K, b.K, 9 * sizeof(double)) == 0;
+}
+
+static int count_runs(const fp_object_batch *objs, int n_obj) {
   int k = 0;
-  for (int o = 0; o < n_obj; ++o) k += objs[o].n > 0;
+  for (int o = 0; o < n_obj;) {
+    int e = o + 1, cnt = objs[o].n;
+    while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
+    k += cnt > 0;
+    o = e;
+  }
   return k;
 }
 
@@ -439,21 +451,29 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
     TAKE(pose_tmp, float, (size_t)N * 16);
     TAKE(net_in, f16, (size_t)2 * N * img);
     float *tr = d_trans ? d_trans : trans, *ro = d_rot ? d_rot : rot;
-    const int n_active = count_active(objs, n_obj);
+    const int n_runs = count_runs(objs, n_obj);
     for (int it = 0; it < iteration; ++it) {
       int off = 0, k = 0;
-      ObjectFanout fo(ctx, s, n_active);
-      for (int o = 0; o < n_obj; ++o) {       // per-object: crop window, render (side A), observed crop (side B)
-        const fp_object_batch &ob = objs[o];
-        if (ob.n == 0) continue;
-        hipStream_t so = fo.stream_for(k++);
-        float *p = d_poses + (size_t)off * 16;
-        FP_TRY(launch_crop_window_tf(p, ob.n, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
-        FP_TRY(fp_render_net(ctx, ob.mesh, p, ob.n, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
-                             cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, so));
-        FP_TRY(fp_crop_observed(ctx, ob.d_rgb, ob.d_geom, ob.H, ob.W, ob.K, tf + (size_t)off * 9, p, ob.n, 160, 160, 0, ob.mesh_diameter,
-                                cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, so));
-        off += ob.n;
+      ObjectFanout fo(ctx, s, n_runs);
+      for (int o = 0; o < n_obj;) {       // per run of like objects: crop windows + render (side A); per object: observed crop (side B)
+        int e = o + 1, cnt = objs[o].n;
+        while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
+        if (cnt > 0) {
+          const fp_object_batch &ob = objs[o];
+          hipStream_t so = fo.stream_for(k++);
+          float *p = d_poses + (size_t)off * 16;
+          FP_TRY(launch_crop_window_tf(p, cnt, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
+          FP_TRY(fp_render_net(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
+                               cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, so));
+          for (int q = o; q < e; ++q) {
+            const fp_object_batch &oq = objs[q];
+            if (oq.n == 0) continue;
+            FP_TRY(fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, oq.n, 160, 160, 0,
+                                    oq.mesh_diameter, cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, so));
+            off += oq.n;
+          }
+        }
+        o = e;
       }
       FP_TRY(fo.join());
       FP_TRY(fp_refine_forward(ctx, net, net_in, N, tr, ro, s));     // ONE network pass for every object
@@ -502,18 +522,26 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
     TAKE(bbox, float, (size_t)N * 4);
     TAKE(net_in, f16, (size_t)2 * N * img);
     int off = 0, k = 0;
-    ObjectFanout fo(ctx, s, count_active(objs, n_obj));
-    for (int o = 0; o < n_obj; ++o) {
-      const fp_object_batch &ob = objs[o];
-      if (ob.n == 0) continue;
-      hipStream_t so = fo.stream_for(k++);
-      const float *p = d_poses + (size_t)off * 16;
-      FP_TRY(launch_crop_window_tf(p, ob.n, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
-      FP_TRY(fp_render_net(ctx, ob.mesh, p, ob.n, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
-                           net_in + (size_t)off * img, so));
-      FP_TRY(fp_crop_observed(ctx, ob.d_rgb, ob.d_geom, ob.H, ob.W, ob.K, tf + (size_t)off * 9, p, ob.n, 160, 160, 1, ob.mesh_diameter,
-                              normalize_xyz, 1, net_in + ((size_t)N + off) * img, so));
-      off += ob.n;
+    ObjectFanout fo(ctx, s, count_runs(objs, n_obj));
+    for (int o = 0; o < n_obj;) {
+      int e = o + 1, cnt = objs[o].n;
+      while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
+      if (cnt > 0) {
+        const fp_object_batch &ob = objs[o];
+        hipStream_t so = fo.stream_for(k++);
+        const float *p = d_poses + (size_t)off * 16;
+        FP_TRY(launch_crop_window_tf(p, cnt, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
+        FP_TRY(fp_render_net(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
+                             net_in + (size_t)off * img, so));
+        for (int q = o; q < e; ++q) {
+          const fp_object_batch &oq = objs[q];
+          if (oq.n == 0) continue;
+          FP_TRY(fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, oq.n, 160, 160, 1,
+                                  oq.mesh_diameter, normalize_xyz, 1, net_in + ((size_t)N + off) * img, so));
+          off += oq.n;
+        }
+      }
+      o = e;
     }
     FP_TRY(fo.join());
     FP_TRY(fp_score_features(ctx, net, net_in, N, d_feats, s));

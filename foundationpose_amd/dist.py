@@ -22,6 +22,18 @@ def shard_ranges(n, world):
   return [(min(r * s, n), min((r + 1) * s, n)) for r in range(world)]
 
 
+def rotated_shard(obj, rank, world):
+  """Shard index of object `obj` that `rank` processes in a multi-object job.  Contiguous shards of ceil(n/world) leave
+  the last shard short (252 = 7 x 32 + 28); rotating the assignment by the object index gives every rank of an
+  8-object job exactly 252 hypotheses instead of 256 on seven ranks and 224 on the last."""
+  return (rank + obj) % world
+
+
+def gather_order(obj, world):
+  """Rank that holds shard s of object `obj` (inverse of rotated_shard), for s = 0..world-1."""
+  return [(s - obj) % world for s in range(world)]
+
+
 def pack_rows(feats, poses, shard_size):
   """(k,512) feats + (k,4,4) poses -> (shard_size, 528) rows, zero padded (k <= shard_size)."""
   k = feats.shape[0]

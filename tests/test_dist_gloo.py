@@ -37,6 +37,20 @@ def test_pack_unpack_roundtrip_single_process():
   assert torch.equal(f2, feats) and torch.equal(p2, poses)
 
 
+def test_rotated_shards_balance_8_ranks():
+  """8 objects x 252 hypotheses over 8 ranks: with the shard index rotated by the object index every rank handles exactly
+  252 hypotheses (contiguous assignment: 256 on seven ranks, 224 on the last), every shard of every object is handled
+  exactly once, and gather_order inverts the rotation."""
+  from foundationpose_amd.dist import gather_order, rotated_shard, shard_ranges
+  n, world = 252, 8
+  ranges = shard_ranges(n, world)
+  for rank in range(world):
+    assert sum(b - a for a, b in (ranges[rotated_shard(o, rank, world)] for o in range(world))) == n
+  for o in range(world):
+    assert sorted(rotated_shard(o, r, world) for r in range(world)) == list(range(world))
+    assert all(rotated_shard(o, gather_order(o, world)[s], world) == s for s in range(world))
+
+
 def _free_port():
   s = socket.socket()
   s.bind(('127.0.0.1', 0))
@@ -50,19 +64,20 @@ def _worker(rank, world, port, cases, out_q):
   os.environ['MASTER_ADDR'] = '127.0.0.1'
   os.environ['MASTER_PORT'] = str(port)
   dist.init_process_group('gloo', rank=rank, world_size=world)
-  from foundationpose_amd.dist import all_gather_rows, pack_rows, shard_ranges, unpack_rows
+  from foundationpose_amd.dist import all_gather_rows, gather_order, pack_rows, rotated_shard, shard_ranges, unpack_rows
   for n, n_obj in cases:
     shard = -(-n // world)
     g = torch.Generator().manual_seed(123)            # every rank can regenerate the full truth
     feats = torch.randn((n_obj, n, 512), generator=g)
     poses = torch.randn((n_obj, n, 4, 4), generator=g)
-    a, b = shard_ranges(n, world)[rank]
-    # bench.py layout: every object's shard of this rank, stacked, ONE all-gather
-    rows = torch.cat([pack_rows(feats[o, a:b], poses[o, a:b], shard) for o in range(n_obj)], 0)
+    ranges = shard_ranges(n, world)
+    # bench.py layout: this rank's (rotated) shard of every object, stacked, ONE all-gather
+    sl = [ranges[rotated_shard(o, rank, world)] for o in range(n_obj)]
+    rows = torch.cat([pack_rows(feats[o, a:b], poses[o, a:b], shard) for o, (a, b) in enumerate(sl)], 0)
     gathered = all_gather_rows(rows).reshape(world, n_obj, shard, -1)
     ok = True
     for o in range(n_obj):
-      f2, p2 = unpack_rows(gathered[:, o].reshape(world * shard, -1), n, world)
+      f2, p2 = unpack_rows(gathered[gather_order(o, world), o].reshape(world * shard, -1), n, world)
       ok = ok and torch.equal(f2, feats[o]) and torch.equal(p2, poses[o])
     # the cross-hypothesis tail sees identical inputs on every rank -> identical argmax
     am = int((gathered[..., :512].sum(-1)).reshape(-1).argmax())

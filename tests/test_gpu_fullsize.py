@@ -149,8 +149,14 @@ def test_multi_object_pass_equals_per_object_passes(env):
                ob_in_cams=env['poses'][:100]),
           dict(rgb=sc2['rgb'], depth=depth2, xyz_map=G.depth2xyzmap(depth2, sc2['K']), K=sc2['K'], mesh_tensors=env['mt'],
                mesh_diameter=sc['diameter'], ob_in_cams=torch.from_numpy(util.hypotheses(sc2, 152)).cuda())]
+  # objects 0 and 1 share mesh and camera (their crop windows and renders merge into one launch); object 2 has another
+  # camera matrix and starts a launch of its own
+  K3 = sc['K'].copy()
+  K3[0, 0] *= 1.03
+  K3[1, 2] += 2.5
+  objs.append(dict(objs[0], K=K3, xyz_map=G.depth2xyzmap(env['depth'], K3), ob_in_cams=env['poses'][100:140]))
   refined = refiner.predict_multi(objs, iteration=2)
-  assert refined.shape == (252, 4, 4)
+  assert refined.shape == (292, 4, 4)
   parts = []
   for ob in objs:
     p, _ = refiner.predict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], ob_in_cams=ob['ob_in_cams'], xyz_map=ob['xyz_map'],
