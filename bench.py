@@ -63,15 +63,14 @@ def build_job(device, n_objects, rank):
   return est, objects
 
 
-def step(est, objects, world, rank):
-  """One register-core pass over all objects; returns per-object (best index, best pose) finalised on
-  the owning rank (object o is finalised by rank o % world)."""
-  from foundationpose_amd.dist import all_gather_rows, gather_order, pack_rows, rotated_shard, shard_ranges, unpack_rows
+def step_local(est, objects, world, rank):
+  """The per-rank part of a step: this rank's shard of EVERY object through refinement and feature extraction as one batch.
+  Returns the [feat | pose] row block this rank contributes to the all-gather, (n_objects * shard, 528)."""
+  from foundationpose_amd.dist import pack_rows, rotated_shard, shard_ranges
   shard = math.ceil(N_HYP / world)
   ranges = shard_ranges(N_HYP, world)
-  # this rank's shard of EVERY object goes through the networks as one batch (render / crop stay per object); the shard
-  # index is rotated by the object index so that the short last shard (252 = 7 x 32 + 28) lands on a different rank for
-  # every object: each rank of an 8-GPU job handles exactly 252 hypotheses
+  # the shard index is rotated by the object index so that the short last shard (252 = 7 x 32 + 28) lands on a different
+  # rank for every object: each rank of an 8-GPU job handles exactly 252 hypotheses
   sl = [ranges[rotated_shard(o, rank, world)] for o in range(len(objects))]
   refined = est.refiner.predict_multi([dict(rgb=ob['rgb'], xyz_map=ob['xyz'], K=ob['K'], mesh_tensors=est.mesh_tensors,
                                             mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b])
@@ -82,21 +81,30 @@ def step(est, objects, world, rank):
   feats = est.scorer.extract_features_multi([dict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], mesh_tensors=est.mesh_tensors,
                                                   mesh_diameter=est.diameter, ob_in_cams=refined[offs[o]:offs[o + 1]])
                                              for o, ob in enumerate(objects)])
-  blocks = [(feats[offs[o]:offs[o + 1]], refined[offs[o]:offs[o + 1]]) for o in range(len(objects))]
+  return torch.cat([pack_rows(feats[offs[o]:offs[o + 1]], refined[offs[o]:offs[o + 1]], shard) for o in range(len(objects))], 0)
+
+
+def step_finalize(est, objects, world, rank, gathered):
+  """The cross-hypothesis tail of the objects this rank finalises (object o: rank o % world).  gathered: every rank's row
+  block, (world * n_objects * shard, 528) in rank order.  Returns {object: (argmax, poses (252,4,4))}."""
+  from foundationpose_amd.dist import gather_order, unpack_rows
+  shard = math.ceil(N_HYP / world)
+  gathered = gathered.reshape(world, len(objects), shard, -1)
   results = {}
-  if world > 1:
-    rows = torch.cat([pack_rows(f, p, shard) for f, p in blocks], 0)          # (O*shard, 528)
-    gathered = all_gather_rows(rows).reshape(world, len(objects), shard, -1)     # ONE all-gather per step
-  for o, ob in enumerate(objects):
+  for o in range(len(objects)):
     if o % world != rank:
       continue
-    if world > 1:
-      feats_all, poses_all = unpack_rows(gathered[gather_order(o, world), o].reshape(world * shard, -1), N_HYP, world)
-    else:
-      feats_all, poses_all = blocks[o]
+    feats_all, poses_all = unpack_rows(gathered[gather_order(o, world), o].reshape(world * shard, -1), N_HYP, world)
     logits, am = est.scorer.score_tail(feats_all, L=N_HYP)
     results[o] = (am, poses_all)
   return results
+
+
+def step(est, objects, world, rank):
+  """One register-core pass over all objects: local part, ONE all-gather of [feat | pose] rows, tail on the owning rank."""
+  from foundationpose_amd.dist import all_gather_rows
+  rows = step_local(est, objects, world, rank)
+  return step_finalize(est, objects, world, rank, all_gather_rows(rows) if world > 1 else rows)
 
 
 def pmc_traffic():

@@ -13,22 +13,10 @@ def main():
   est, objects_all = bench.build_job(device, n_objects=max(worlds), rank=0)
   est.refiner.ctx.reserve(bench.N_HYP + 8)
   for W in worlds:
-    from foundationpose_amd.dist import rotated_shard, shard_ranges
     objects = objects_all[:W]
-    ranges = shard_ranges(bench.N_HYP, W)
-    sl = [ranges[rotated_shard(o, 0, W)] for o in range(W)]            # rank 0's shard of every object (as bench.step)
-    offs = [0]
-    for a, b in sl:
-      offs.append(offs[-1] + (b - a))
-    n = offs[-1] / W
 
     def step():
-      refined = est.refiner.predict_multi([dict(rgb=ob['rgb'], xyz_map=ob['xyz'], K=ob['K'], mesh_tensors=est.mesh_tensors,
-                                                mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b])
-                                           for ob, (a, b) in zip(objects, sl)], iteration=bench.ITER)
-      return est.scorer.extract_features_multi([dict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], mesh_tensors=est.mesh_tensors,
-                                                     mesh_diameter=est.diameter, ob_in_cams=refined[offs[o]:offs[o + 1]])
-                                                for o, ob in enumerate(objects)])
+      return bench.step_local(est, objects, W, 0)           # rank 0's (rotated) shard of every object, as in bench.step
     step(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     host = 0.0
@@ -45,7 +33,7 @@ def main():
     cls = {c: ctx.prof_read(c) for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'render')}
     print('   per-class ms (HIP events; overlapping launches on side streams each count their own span): '
           + '  '.join(f"{c} {v['total_ms']:.2f}/{v['launches']}" for c, v in cls.items()))
-    print(f'world {W}: {W} objects, {offs[-1]} hypotheses on this rank: {dt * 1e3:.2f} ms/step  ({offs[-1] / dt:.0f} hyp/s per GPU; '
+    print(f'world {W}: {W} objects, 252 hypotheses on this rank: {dt * 1e3:.2f} ms/step  ({bench.N_HYP / dt:.0f} hyp/s per GPU; '
           f'host enqueue {host / 3 * 1e3:.2f} ms/step)')
 
 

@@ -193,3 +193,25 @@ def test_four_objects_in_one_network_pass_1008(env):
     f_p = torch.empty((N, 512), device='cuda')
     check(lib().fp_score_features(sc.ctx.handle, sc.model.handle, ptr(part), N, ptr(f_p), stream_ptr()))
     assert torch.equal(f_p, feats[o * N:(o + 1) * N])
+
+
+def test_bench_step_sharded_over_4_ranks_equals_one_rank():
+  """bench.py's multi-GPU step with its ranks played one after the other on this GPU (the all-gather replaced by
+  concatenation in rank order): 4 objects x 252 hypotheses over 4 ranks with the rotated shard assignment must finalise
+  every object exactly like a single-rank job does - same argmax, same refined poses, bit for bit."""
+  import bench
+  dev = torch.device('cuda', 0)
+  world = 4
+  est, objects = bench.build_job(dev, n_objects=world, rank=0)
+  est.refiner.ctx.reserve(bench.N_HYP)
+  ref = {}
+  for o in range(world):                                   # truth: each object as a one-rank job
+    ref.update({o: v for v in [bench.step_finalize(est, objects[o:o + 1], 1, 0, bench.step_local(est, objects[o:o + 1], 1, 0))[0]]})
+  rows = [bench.step_local(est, objects, world, r) for r in range(world)]
+  gathered = torch.cat(rows, 0)
+  seen = {}
+  for r in range(world):
+    seen.update(bench.step_finalize(est, objects, world, r, gathered))
+  assert sorted(seen) == list(range(world))
+  for o in range(world):
+    assert int(seen[o][0][0]) == int(ref[o][0][0]) and torch.equal(seen[o][1], ref[o][1])
