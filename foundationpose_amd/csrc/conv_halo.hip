@@ -758,7 +758,16 @@ static void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
   const int rem = n_tiles % slots;
   *n_main = n_tiles;
   *n_tail4 = 0;
-  if (!g_halo_tail || rem == 0 || n_tiles < slots) return;
+  if (!g_halo_tail || rem == 0) return;
+  if (n_tiles < slots) {
+    // less than one round (tracking: 1 .. 64 hypotheses): the launch lasts as long as ONE workgroup, so quarter tiles
+    // (4 x the workgroups, ~0.35 x the time each) win as long as they still fit one round
+    if (4 * n_tiles <= slots) {
+      *n_main = 0;
+      *n_tail4 = 4 * n_tiles;
+    }
+    return;
+  }
   const double cost_whole = 1.0, cost_quarter = 0.35 * ((4 * rem + slots - 1) / slots);
   if (cost_quarter < cost_whole) {
     *n_main = n_tiles - rem;
