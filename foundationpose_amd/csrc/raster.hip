@@ -115,6 +115,48 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     Vtx v1 = xform_vertex(m.pos, i1, M, hw, hh);
     Vtx v2 = xform_vertex(m.pos, i2, M, hw, hh);
     if (!(v0.ok && v1.ok && v2.ok)) continue;
+    // Triangles whose snapped coordinates stay within +-1024 px (all but the ones far outside the crop) take the same
+    // integer edge functions in 32-bit arithmetic: |X|,|Y| < 2^14 -> differences < 2^15, products < 2^30, sums < 2^31.
+    // The values are the same integers as in the 64-bit path, so coverage, barycentrics and depth keys are bit-identical.
+    const int amax = max(max(max(abs(v0.X), abs(v0.Y)), max(abs(v1.X), abs(v1.Y))), max(abs(v2.X), abs(v2.Y)));
+    if (amax < 16384) {
+      const int X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
+      int area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+      if (area == 0) continue;
+      const int sg = area > 0 ? 1 : -1;
+      area *= sg;
+      const int xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+      const int ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+      int ia = (xmin - 8 + 15) >> 4, ib = (xmax - 8) >> 4, ja = (ymin - 8 + 15) >> 4, jb = (ymax - 8) >> 4;
+      ia = max(ia, 0);
+      ja = max(ja, row0);
+      ib = min(ib, Wo - 1);
+      jb = min(jb, row1 - 1);
+      if (ia > ib || ja > jb) continue;
+      const int dx0 = sg * (X2 - X1), dy0 = sg * (Y2 - Y1);
+      const int dx1 = sg * (X0 - X2), dy1 = sg * (Y0 - Y2);
+      const int dx2 = sg * (X1 - X0), dy2 = sg * (Y1 - Y0);
+      const bool tl0 = (dy0 > 0) || (dy0 == 0 && dx0 < 0);
+      const bool tl1 = (dy1 > 0) || (dy1 == 0 && dx1 < 0);
+      const bool tl2 = (dy2 > 0) || (dy2 == 0 && dx2 < 0);
+      const float fa = (float)area;
+      for (int j = ja; j <= jb; ++j) {
+        const int Py = 16 * j + 8;
+        for (int i = ia; i <= ib; ++i) {
+          const int Px = 16 * i + 8;
+          const int e0 = dx0 * (Py - Y1) - dy0 * (Px - X1);
+          const int e1 = dx1 * (Py - Y2) - dy1 * (Px - X2);
+          const int e2 = dx2 * (Py - Y0) - dy2 * (Px - X0);
+          if (!((e0 > 0 || (e0 == 0 && tl0)) && (e1 > 0 || (e1 == 0 && tl1)) && (e2 > 0 || (e2 == 0 && tl2)))) continue;
+          const float b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+          const float zp = fmaf(b2, v2.zn, fmaf(b1, v1.zn, b0 * v0.zn));
+          if (!(zp >= -1.f && zp <= 1.f)) continue;
+          const unsigned long long key = ((unsigned long long)ordered_key(zp) << 32) | (unsigned)t;
+          atomicMin(&zbuf[(j - row0) * Wo + i], key);
+        }
+      }
+      continue;
+    }
     long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
     long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
     if (area == 0) continue;
@@ -169,16 +211,31 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
       Vtx v0 = xform_vertex(m.pos, i0, M, hw, hh);
       Vtx v1 = xform_vertex(m.pos, i1, M, hw, hh);
       Vtx v2 = xform_vertex(m.pos, i2, M, hw, hh);
-      long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
-      long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
-      long long sg = area > 0 ? 1 : -1;
-      area *= sg;
-      long long Px = 16ll * i + 8, Py = 16ll * j + 8;
-      long long e0 = sg * ((X2 - X1) * (Py - Y1) - (Y2 - Y1) * (Px - X1));
-      long long e1 = sg * ((X0 - X2) * (Py - Y2) - (Y0 - Y2) * (Px - X2));
-      long long e2 = sg * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
-      float fa = (float)area;
-      float b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+      float fa, b0, b1, b2;
+      const int amax = max(max(max(abs(v0.X), abs(v0.Y)), max(abs(v1.X), abs(v1.Y))), max(abs(v2.X), abs(v2.Y)));
+      if (amax < 16384) {                         // the same integers in 32-bit arithmetic (see pass 1)
+        const int X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
+        int area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+        const int sg = area > 0 ? 1 : -1;
+        area *= sg;
+        const int Px = 16 * i + 8, Py = 16 * j + 8;
+        const int e0 = sg * ((X2 - X1) * (Py - Y1) - (Y2 - Y1) * (Px - X1));
+        const int e1 = sg * ((X0 - X2) * (Py - Y2) - (Y0 - Y2) * (Px - X2));
+        const int e2 = sg * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
+        fa = (float)area;
+        b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+      } else {
+        long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
+        long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+        long long sg = area > 0 ? 1 : -1;
+        area *= sg;
+        long long Px = 16ll * i + 8, Py = 16ll * j + 8;
+        long long e0 = sg * ((X2 - X1) * (Py - Y1) - (Y2 - Y1) * (Px - X1));
+        long long e1 = sg * ((X0 - X2) * (Py - Y2) - (Y0 - Y2) * (Px - X2));
+        long long e2 = sg * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
+        fa = (float)area;
+        b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+      }
       float q0 = b0 / v0.w, q1 = b1 / v1.w, q2 = b2 / v2.w;
       float qs = (q0 + q1) + q2;
       float u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
