@@ -5,7 +5,7 @@ build command.  torch is used only for device memory and the current HIP stream.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 import numpy as np
 import torch

@@ -5,14 +5,13 @@ The whole refinement loop (crop window -> render -> observed crop -> RefineNet -
 host between iterations.
 """
 import logging
-import os
 
 import numpy as np
 import torch
 
 from . import _lib
 from ._lib import FP_NET_REFINE, FpRefineCfg, byref, check, k_ptr, lib, ptr, stream_ptr
-from .Utils import RasterizeContext, _ctx_of, make_mesh_tensors
+from .Utils import _ctx_of, make_mesh_tensors
 from .config import Cfg, load_run_dir
 
 

@@ -1,7 +1,7 @@
 """Per-rank GPU work of `bench.py --gpus W`, emulated on ONE GPU without a process group: W objects, this rank's
 (rotated) shard of each through predict_multi / extract_features_multi (the all-gather and the 0.66-GFLOP
 tail are left out).  Weak scaling holds if the time does not grow with W.    usage: python scripts/bench_rankload.py 1 2 4 8"""
-import math, os, sys, time
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

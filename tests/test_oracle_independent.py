@@ -4,7 +4,6 @@ those pieces "pinned"; they check each restatement against a different implement
 (scipy, closed forms, float64 brute force), so that an error in the oracle cannot hide behind an identical error in the
 HIP kernels that mirror it."""
 import numpy as np
-import pytest
 import torch
 from scipy.spatial.transform import Rotation
 
