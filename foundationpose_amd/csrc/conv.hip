@@ -35,28 +35,28 @@ __device__ __forceinline__ void glds16c(const f16 *g, f16 *l) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");
 }
 
-template <int BM, int KW, bool CIN8>
-__global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f16 *__restrict__ zero_page) {
-  constexpr int XH = C2_BN * C2_BK, WH = BM * C2_BK;      // halfs per stage
+// One workgroup tile: 64 NT pixels x BM couts, 4 waves as 2 (cout halves) x 2 (pixel halves), each wave (BM/2) x 32 NT.
+// NT = 4 -> the 256-pixel main tiles, NT = 1 -> 64-pixel tail tiles (conv_igemm2_kernel).  The accumulation order of an
+// output element does not depend on NT.
+template <int BM, int KW, bool CIN8, int NT>
+__device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__restrict__ zero_page, const int m0, const int c0, f16 *smem) {
+  constexpr int TN = 64 * NT;                              // pixels per workgroup
+  constexpr int XH = TN * C2_BK, WH = BM * C2_BK;          // halfs per stage
   constexpr int SLD = BM + 8;                              // halfs per staged output row
-  extern __shared__ __attribute__((aligned(16))) f16 smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  constexpr int WM = BM / 2, MT = WM / 32, NT = 4;
+  constexpr int WM = BM / 2, MT = WM / 32;
   constexpr int WQ = BM / 64;                              // weight DMA instructions per wave per stage
   const int lr = lane & 31, lh = lane >> 5;
-  const int n_ct = p.Cout / BM;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (L / n_ct) * C2_BN, c0 = (L % n_ct) * BM;
   const int HoWo = p.Ho * p.Wo;
   const int ntaps = p.KH * p.KW;
 
   // ---- DMA source bookkeeping: this lane feeds LDS chunk (px = (q*4+wave)*16 + lane/4, chp = lane&3) ----
   const int chp = lane & 3;
-  long long xbase[4];
-  int iy0[4], ix0[4], xch[4];
+  long long xbase[NT];
+  int iy0[NT], ix0[NT], xch[NT];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < NT; ++q) {
     const int px = (q * 4 + wave) * 16 + (lane >> 2);
     const int m = m0 + px;
     const bool mv = m < p.M;
@@ -74,15 +74,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     const int co = (q * 4 + wave) * 16 + (lane >> 2);
     wsrc[q] = p.w + (size_t)(c0 + co) * p.Kpad + ((chp ^ ((co >> 2) & 3)) * 8);
   }
-  // DMA instruction d of a stage: d = 0..3 the activation gather (pixel group d), d = 4.. the weights
+  // DMA instruction d of a stage: d = 0..NT-1 the activation gather (pixel group d), d = NT.. the weights
   // 1x1 (Linear) layers: a pixel's K-row is contiguous, the gather address of step kt is a fixed per-lane base + kt*64 B
   // (pixels past M read the zero page with stride 0) - no per-step tap / bounds arithmetic in front of the DMA
-  const f16 *xlin[4];
-  int xlin_step[4];
+  const f16 *xlin[NT];
+  int xlin_step[NT];
   const bool lin = KW == 1 && !CIN8 && p.stride == 1 && p.pad == 0;     // output pixel m reads input pixel m
   if (lin) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NT; ++q) {
       const int m = m0 + (q * 4 + wave) * 16 + (lane >> 2);
       const bool mv = m < p.M;
       xlin[q] = mv ? p.in + (size_t)m * p.Cin + xch[q] * 8 : zero_page;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
   }
   auto stage_one = [&](int kt, int buf, int d) __attribute__((always_inline)) {
     f16 *xs = smem + buf * (XH + WH), *ws = xs + XH;
-    if (d < 4) {
+    if (d < NT) {
       const int q = d;
       if (lin) {
         glds16c(xlin[q] + kt * xlin_step[q], xs + (q * 4 + wave) * 512);
@@ -112,13 +112,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
       const f16 *src = ok ? p.in + xbase[q] + ((long long)iy * p.W + ix) * p.Cin + ci : zero_page;
       glds16c(src, xs + (q * 4 + wave) * 512);
     } else {
-      const int q = d - 4;
+      const int q = d - NT;
       glds16c(wsrc[q] + (size_t)kt * C2_BK, ws + (q * 4 + wave) * 512);
     }
   };
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int d = 0; d < 4 + WQ; ++d) stage_one(kt, buf, d);
+    for (int d = 0; d < NT + WQ; ++d) stage_one(kt, buf, d);
   };
 
   // ---- fragment bases (swizzled rows: chunk ^ ((row>>2)&3); rows +32 keep the same swizzle) ----
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     for (int ks = 0; ks < 2; ++ks) wa[ks] = co * 32 + (((ks * 2 + lh) ^ ((co >> 2) & 3)) * 8);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int px = wn * 128 + j * 32 + lr;
+      const int px = wn * (32 * NT) + j * 32 + lr;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) xa[j][ks] = px * 32 + (((ks * 2 + lh) ^ ((px >> 2) & 3)) * 8);
     }
@@ -146,18 +146,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
   const int nk = p.Kpad / C2_BK;
   // 3-deep LDS-DMA ring: K-steps kt+1 and kt+2 stay in flight across the barrier (counted vmcnt + raw s_barrier;
   // a __syncthreads() would drain them).  Every wave issues exactly DMAW instructions per stage.
-  constexpr int DMAW = 4 + WQ;
-  static_assert(DMAW == 5 || DMAW == 6, "vmcnt immediates below assume 5 or 6 DMA instructions per wave per stage");
+  constexpr int DMAW = NT + WQ;
   stage(0, 0);
   if (nk > 1) stage(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt % 3;
-    if (kt + 1 < nk) {
-      if (DMAW == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMAW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // stage kt landed for every wave; slot (kt+2)%3 was last read in step kt-1: free
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);
@@ -192,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     __syncthreads();
     f16 *stage = smem;
     constexpr int CPR = BM / 8;           // 16-byte chunks per staged row
-    constexpr int NCH = C2_BN * CPR / 256;
+    constexpr int NCH = TN * CPR / 256;
     constexpr int RB = NCH < 8 ? NCH : 8;
     if (p.res) {
 #pragma unroll
@@ -220,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
       for (int rg = 0; rg < 4; ++rg) bvs[i][rg] = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int pxl = wn * 128 + j * 32 + lr;
+      const int pxl = wn * (32 * NT) + j * 32 + lr;
       float4 pvs[MT][4];
       if (p.post_add) {
         const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
@@ -294,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
     for (int rg = 0; rg < 4; ++rg) bvd[i][rg] = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int m = m0 + wn * 128 + j * 32 + lr;
+    const int m = m0 + wn * (32 * NT) + j * 32 + lr;
     if (m >= p.M) continue;
     const bool hi = m >= p.split_m;
     const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
@@ -352,9 +347,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
   }
 }
 
+// Grid = n_main workgroups of 256 px x BM co, then n_tail4 workgroups of 64 px covering the LAST main-size tiles cut in four
+// (see conv3x3_halo kernels: at N=252 these layers have 1576 or 3150 tiles for 512 slots - a last round that is 8-15 % full).
 template <int BM, int KW, bool CIN8>
-static int launch_two(const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
-  dim3 grid(((a.M + C2_BN - 1) / C2_BN) * (a.Cout / BM));
+__global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f16 *__restrict__ zero_page, int n_main) {
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];
+  const int n_ct = p.Cout / BM;
+  if ((int)blockIdx.x < n_main) {
+    const int L = xcd_remap(blockIdx.x, n_main);
+    igemm2_tile<BM, KW, CIN8, 4>(p, zero_page, (L / n_ct) * C2_BN, (L % n_ct) * BM, smem);
+  } else {
+    const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
+    const int L = n_main + (t >> 2);
+    const int m0 = (L / n_ct) * C2_BN + (t & 3) * (C2_BN / 4);
+    if (m0 >= p.M) return;
+    igemm2_tile<BM, KW, CIN8, 1>(p, zero_page, m0, (L % n_ct) * BM, smem);
+  }
+}
+
+void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4);      // conv_halo.hip: main / quarter-tile split
+
+template <int BM, int KW, bool CIN8>
+static int launch_two(fp_ctx *ctx, const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
+  const int n_tiles = ((a.M + C2_BN - 1) / C2_BN) * (a.Cout / BM);
+  int n_main, n_tail4;
+  halo_split(n_tiles, 2 * ctx->num_cu, &n_main, &n_tail4);
   constexpr int main_b = 3 * (C2_BN * C2_BK + BM * C2_BK) * 2, epi_b = C2_BN * (BM + 8) * 2;
   constexpr int lds = main_b > epi_b ? main_b : epi_b;
   static bool attr_set = false;
@@ -363,7 +380,7 @@ static int launch_two(const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
     attr_set = true;
   }
   FP_REQUIRE(a.out_mode != 0 || (a.out_ld % 8 == 0 && a.coff_hi % 8 == 0), "conv: out_ld/coff must be multiples of 8 for fp16 output");
-  hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8>), grid, dim3(256), lds, s, a, zero_page);
+  hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8>), dim3(n_main + n_tail4), dim3(256), lds, s, a, zero_page, n_main);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
@@ -388,9 +405,9 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const f16 *zp = (const f16 *)ctx->zero_page;
   if (a.Cin == 8) {
     FP_REQUIRE(a.KW == 7, "conv: Cin=8 path is the 7x7 stem");
-    return bm128 ? launch_two<128, 7, true>(a, zp, s) : launch_two<64, 7, true>(a, zp, s);
+    return bm128 ? launch_two<128, 7, true>(ctx, a, zp, s) : launch_two<64, 7, true>(ctx, a, zp, s);
   }
-  if (a.KW == 3) return bm128 ? launch_two<128, 3, false>(a, zp, s) : launch_two<64, 3, false>(a, zp, s);
-  if (a.KW == 1) return bm128 ? launch_two<128, 1, false>(a, zp, s) : launch_two<64, 1, false>(a, zp, s);
+  if (a.KW == 3) return bm128 ? launch_two<128, 3, false>(ctx, a, zp, s) : launch_two<64, 3, false>(ctx, a, zp, s);
+  if (a.KW == 1) return bm128 ? launch_two<128, 1, false>(ctx, a, zp, s) : launch_two<64, 1, false>(ctx, a, zp, s);
   FP_REQUIRE(false, "conv: unsupported configuration KW=%d Cin=%d", a.KW, a.Cin);
 }

@@ -754,7 +754,7 @@ int g_halo_npw = 4;    // FP_HALO_NPW=2 selects the 4-wave / 2-workgroups-per-CU
 
 // main/tail split: whole rounds of `slots` main tiles stay; the remainder is cut in four when that shortens the last round
 // (a quarter tile costs ~0.35 of a main tile: less operand reuse), i.e. when the remainder fills < ~70 % of a round.
-static void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
+void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
   const int rem = n_tiles % slots;
   *n_main = n_tiles;
   *n_tail4 = 0;
