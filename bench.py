@@ -212,6 +212,8 @@ def main():
         classes[c] = {'ms_per_step': r['total_ms'] / args.steps, 'launches_per_step': r['launches'] / args.steps,
                       'tflops': (r['flops'] / (r['total_ms'] * 1e-3) / 1e12) if r['flops'] else None}
     out['kernel_classes'] = classes       # HIP-event time per kernel class (same events as the roofline figure)
+    out['kernel_classes_note'] = ('linear / attention: RefineNet runs its two transformer heads on two streams, their launches overlap '
+                                  'and each counts its own span (sum > wall time); the convolution classes and render run alone')
     if not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

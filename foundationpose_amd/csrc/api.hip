@@ -20,13 +20,14 @@ extern "C" int fp_version(void) { return 100; }
 
 // ---- context / arena ---------------------------------------------------------------------------
 size_t fp_arena_bytes_for(int n_hyp) {
-  // per hypothesis: net input 0.82 MB, encoder activations ~7.8 MB, tokens + attention ~4.1 MB (see DESIGN.md "HBM layout")
-  return (size_t)n_hyp * (size_t)(14u << 20) + ((size_t)64 << 20);
+  // per hypothesis: net input 0.82 MB (x2 sides) + the forward's buffers (fp_arena_inner_bytes)
+  return (size_t)n_hyp * (size_t)(17u << 20) + ((size_t)64 << 20);
 }
 
 size_t fp_arena_inner_bytes(int n_hyp) {
   // exact sum of the forward's buffers is 11,485,184 B per hypothesis (DESIGN.md "HBM layout")
-  return (size_t)n_hyp * (size_t)(12u << 20) + ((size_t)8 << 20);
+  // + 2.9 MB per hypothesis for the second transformer head's buffers (the two heads of RefineNet run side by side)
+  return (size_t)n_hyp * (size_t)(15u << 20) + ((size_t)8 << 20);
 }
 
 int fp_arena_ensure(fp_ctx *ctx, size_t bytes) {
@@ -369,50 +370,6 @@ static int check_objs(const fp_object_batch *objs, int n_obj, int *total) {
   return FP_OK;
 }
 
-// Fork / join of the per-object stages of a multi-object pass onto the context's side streams (single object: everything
-// stays on the launch stream).
-struct ObjectFanout {
-  fp_ctx *ctx;
-  hipStream_t main;
-  bool fan;
-  bool used[fp_ctx::NSIDE] = {};
-  int rc = FP_OK;
-  ObjectFanout(fp_ctx *c, hipStream_t s, int n_active) : ctx(c), main(s), fan(n_active > 1) {
-    if (!fan) return;
-    if (!ctx->side_ready) {
-      bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
-      for (int i = 0; ok && i < fp_ctx::NSIDE; ++i)
-        ok = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
-      if (!ok) {
-        fan = false;          // no side streams: run the objects one after the other
-        return;
-      }
-      ctx->side_ready = true;
-    }
-    if (hipEventRecord(ctx->ev_fork, main) != hipSuccess) fan = false;
-  }
-  hipStream_t stream_for(int k) {
-    if (!fan) return main;
-    const int i = k % fp_ctx::NSIDE;
-    if (!used[i]) {
-      used[i] = true;
-      if (hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0) != hipSuccess) rc = FP_EHIP;
-    }
-    return ctx->side[i];
-  }
-  int join() {
-    if (fan)
-      for (int i = 0; i < fp_ctx::NSIDE; ++i)
-        if (used[i]) {
-          if (hipEventRecord(ctx->ev_join[i], ctx->side[i]) != hipSuccess || hipStreamWaitEvent(main, ctx->ev_join[i], 0) != hipSuccess) rc = FP_EHIP;
-          used[i] = false;
-        }
-    if (rc != FP_OK) fp_set_error("multi-object pass: stream fork/join failed");
-    return rc;
-  }
-};
-
 // Objects whose crop windows and renders can share one launch: same mesh, camera and frame size (their hypotheses are
 // contiguous in d_poses).  A rank of the sharded multi-GPU job holds a slice of several objects of ONE mesh: one 252-hypothesis
 // render instead of eight 32-hypothesis ones that each fill a quarter of the chip.
@@ -454,7 +411,7 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
     const int n_runs = count_runs(objs, n_obj);
     for (int it = 0; it < iteration; ++it) {
       int off = 0, k = 0;
-      ObjectFanout fo(ctx, s, n_runs);
+      StreamFanout fo(ctx, s, n_runs);
       for (int o = 0; o < n_obj;) {       // per run of like objects: crop windows + render (side A); per object: observed crop (side B)
         int e = o + 1, cnt = objs[o].n;
         while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
@@ -522,7 +479,7 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
     TAKE(bbox, float, (size_t)N * 4);
     TAKE(net_in, f16, (size_t)2 * N * img);
     int off = 0, k = 0;
-    ObjectFanout fo(ctx, s, count_runs(objs, n_obj));
+    StreamFanout fo(ctx, s, count_runs(objs, n_obj));
     for (int o = 0; o < n_obj;) {
       int e = o + 1, cnt = objs[o].n;
       while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;

@@ -97,6 +97,51 @@ int fp_arena_ensure(fp_ctx *ctx, size_t bytes);
 size_t fp_arena_bytes_for(int n_hyp);     // whole refine/score pass (outer buffers + network)
 size_t fp_arena_inner_bytes(int n_hyp);   // network forward only
 
+// Fork / join of independent kernel chains onto the context's side streams: the per-object stages of a multi-object pass,
+// the two transformer heads of RefineNet.  With fewer than two chains everything stays on the launch stream.
+struct StreamFanout {
+  fp_ctx *ctx;
+  hipStream_t main;
+  bool fan;
+  bool used[fp_ctx::NSIDE] = {};
+  int rc = FP_OK;
+  StreamFanout(fp_ctx *c, hipStream_t s, int n_active) : ctx(c), main(s), fan(n_active > 1) {
+    if (!fan) return;
+    if (!ctx->side_ready) {
+      bool ok = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; ok && i < fp_ctx::NSIDE; ++i)
+        ok = hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        fan = false;          // no side streams: run the objects one after the other
+        return;
+      }
+      ctx->side_ready = true;
+    }
+    if (hipEventRecord(ctx->ev_fork, main) != hipSuccess) fan = false;
+  }
+  hipStream_t stream_for(int k) {
+    if (!fan) return main;
+    const int i = k % fp_ctx::NSIDE;
+    if (!used[i]) {
+      used[i] = true;
+      if (hipStreamWaitEvent(ctx->side[i], ctx->ev_fork, 0) != hipSuccess) rc = FP_EHIP;
+    }
+    return ctx->side[i];
+  }
+  int join() {
+    if (fan)
+      for (int i = 0; i < fp_ctx::NSIDE; ++i)
+        if (used[i]) {
+          if (hipEventRecord(ctx->ev_join[i], ctx->side[i]) != hipSuccess || hipStreamWaitEvent(main, ctx->ev_join[i], 0) != hipSuccess) rc = FP_EHIP;
+          used[i] = false;
+        }
+    if (rc != FP_OK) fp_set_error("stream fork/join failed");
+    return rc;
+  }
+};
+
+
 // profiling hooks (events on the launch stream)
 struct ProfScope {
   fp_ctx *ctx;

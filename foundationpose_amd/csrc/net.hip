@@ -385,24 +385,36 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     const f16 *in = (const f16 *)d_net_in;
     FP_TRY(run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, &tok, s));
     const int M = N * 400;
-    TAKE(qk, f16, (size_t)M * 1024);
-    TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
-    TAKE(att, f16, (size_t)M * 512);
-    TAKE(y16, f16, (size_t)M * 512);   // pre-LayerNorm sums, fp16 like the reference's autocast path
-    TAKE(x1, f16, (size_t)M * 512);
-    TAKE(ff, f16, (size_t)M * 512);
-    TAKE(lnpart, float, (size_t)N * 8 * 512);
+    // The translation and rotation heads are independent transformer layers on the same tokens: each gets its own
+    // buffers and its own stream, so the tail of one head's kernels overlaps the other's (their launches are 3.08 rounds of
+    // workgroups each)
     float *outs[2] = {d_trans + (size_t)s0 * 3, d_rot + (size_t)s0 * net->heads[1].out_dim};
+    f16 *qk[2], *vt[2], *att[2], *y16[2], *x1[2], *ff[2];
+    float *lnpart[2];
+    for (int h = 0; h < 2; ++h) {
+      TAKE(qk_, f16, (size_t)M * 1024);
+      TAKE(vt_, f16, (size_t)N * 4 * 128 * 416);
+      TAKE(att_, f16, (size_t)M * 512);
+      TAKE(y16_, f16, (size_t)M * 512);   // pre-LayerNorm sums, fp16 like the reference's autocast path
+      TAKE(x1_, f16, (size_t)M * 512);
+      TAKE(ff_, f16, (size_t)M * 512);
+      TAKE(lnpart_, float, (size_t)N * 8 * 512);
+      qk[h] = qk_, vt[h] = vt_, att[h] = att_, y16[h] = y16_, x1[h] = x1_, ff[h] = ff_, lnpart[h] = lnpart_;
+    }
+    static const bool serial_heads = getenv("FP_HEADS_SERIAL") != nullptr;      // A/B timing knob
+    StreamFanout fo(ctx, s, serial_heads ? 1 : 2);
     for (int h = 0; h < 2; ++h) {
       const HeadW &H = net->heads[h];
-      FP_TRY(run_mha_core(ctx, H.qk, H.v, tok, N, qk, vt, att, s));
+      hipStream_t sh = h == 0 ? s : fo.stream_for(0);
+      FP_TRY(run_mha_core(ctx, H.qk, H.v, tok, N, qk[h], vt[h], att[h], sh));
       Conv2dCall c;
-      c = Conv2dCall{att, M, 1, 1, &H.out}; c.relu = 0; c.res = tok; c.out = y16; FP_TRY(run_conv(ctx, c, s));
-      FP_TRY(launch_layernorm_h(y16, H.ln1g, H.ln1b, M, x1, s));
-      c = Conv2dCall{x1, M, 1, 1, &H.ff1}; c.relu = 1; c.out = ff; FP_TRY(run_conv(ctx, c, s));
-      c = Conv2dCall{ff, M, 1, 1, &H.ff2}; c.relu = 0; c.res = x1; c.out = y16; FP_TRY(run_conv(ctx, c, s));
-      FP_TRY(launch_ln_mean_head_h(y16, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], lnpart, s));
+      c = Conv2dCall{att[h], M, 1, 1, &H.out}; c.relu = 0; c.res = tok; c.out = y16[h]; FP_TRY(run_conv(ctx, c, sh));
+      FP_TRY(launch_layernorm_h(y16[h], H.ln1g, H.ln1b, M, x1[h], sh));
+      c = Conv2dCall{x1[h], M, 1, 1, &H.ff1}; c.relu = 1; c.out = ff[h]; FP_TRY(run_conv(ctx, c, sh));
+      c = Conv2dCall{ff[h], M, 1, 1, &H.ff2}; c.relu = 0; c.res = x1[h]; c.out = y16[h]; FP_TRY(run_conv(ctx, c, sh));
+      FP_TRY(launch_ln_mean_head_h(y16[h], H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], lnpart[h], sh));
     }
+    FP_TRY(fo.join());
     return FP_OK;
   };
   // hypothesis chunks (FP_CHUNK, default: the whole batch in one pass) reuse the SAME arena addresses.  Chunking to keep
