@@ -144,8 +144,8 @@ def cpu_baseline():
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=3)
-  ap.add_argument('--warmup', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=2)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   args = ap.parse_args()
   world = int(os.environ.get('WORLD_SIZE', '1'))
