@@ -214,7 +214,7 @@ def main():
     out['kernel_classes'] = classes       # HIP-event time per kernel class (same events as the roofline figure)
     out['kernel_classes_note'] = ('linear / attention: RefineNet runs its two transformer heads on two streams, their launches overlap '
                                   'and each counts its own span (sum > wall time); the convolution classes and render run alone')
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:        # timed on rank 0 of the single-GPU run only
       out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))
   if world > 1:
