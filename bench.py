@@ -154,11 +154,19 @@ def main():
   assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
   if not torch.cuda.is_available():
     raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+  # FP_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend - rehearses the multi-process flow (rendezvous, barriers,
+  # the all-gather, finalisation) on a one-GPU box; the numbers it prints mean nothing
+  rehearsal = os.environ.get('FP_BENCH_REHEARSAL') == '1'
+  if rehearsal:
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=device)
+    if rehearsal:
+      dist.init_process_group('gloo')
+    else:
+      dist.init_process_group('nccl', device_id=device)
 
   est, objects = build_job(device, n_objects=world, rank=rank)
   ctx = est.refiner.ctx

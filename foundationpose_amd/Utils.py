@@ -327,10 +327,10 @@ def cluster_poses(angle_diff, dist_diff, poses_in, symmetry_tfs):
   """mycpp.cluster_poses (mycpp/src/app/pybind_api.cpp:24-68) - native host code in the HIP library."""
   pin = np.ascontiguousarray(np.asarray(poses_in, dtype=np.float32).reshape(-1, 4, 4))
   sym = np.ascontiguousarray(np.asarray(symmetry_tfs, dtype=np.float32).reshape(-1, 4, 4))
-  print(f'num original candidates = {len(pin)}')
+  logging.info(f'num original candidates = {len(pin)}')      # the reference's C++ prints these two lines to stdout
   out = np.zeros_like(pin)
   n = lib().fp_cluster_poses(float(angle_diff), float(dist_diff), ptr(pin), len(pin), ptr(sym), len(sym), ptr(out))
   if n < 0:
     check(n)
-  print(f'num of pose after clustering: {n}')
+  logging.info(f'num of pose after clustering: {n}')
   return [out[i] for i in range(n)]
