@@ -256,7 +256,6 @@ __global__ void depth2xyz_f64_kernel(const float *__restrict__ depth, int H, int
 __global__ __launch_bounds__(1024) void mask_depth_stats_kernel(const float *__restrict__ depth, const unsigned char *__restrict__ mask, int H,
                                                                 int W, float min_depth, int *__restrict__ out, float *__restrict__ median) {
   __shared__ int s_red[6];
-  __shared__ unsigned s_cnt;
   const int n = H * W, tid = threadIdx.x;
   if (tid == 0) {
     s_red[0] = 0x7fffffff; s_red[1] = -1; s_red[2] = 0x7fffffff; s_red[3] = -1; s_red[4] = 0; s_red[5] = 0;
@@ -280,33 +279,42 @@ __global__ __launch_bounds__(1024) void mask_depth_stats_kernel(const float *__r
     if (tid == 0) *median = 0.f;
     return;
   }
-  // usable depths are >= min_depth > 0: their bit patterns order like the values
-  float vals[2];
-  const int ranks[2] = {(n_us - 1) / 2, n_us / 2};
-  for (int k = 0; k < 2; ++k) {
-    unsigned prefix = 0, rank = (unsigned)ranks[k];
-    for (int b = 31; b >= 0; --b) {
-      __syncthreads();
-      if (tid == 0) s_cnt = 0;
-      __syncthreads();
-      unsigned c0 = 0;
-      const unsigned hi_mask = b == 31 ? 0u : (0xffffffffu << (b + 1));
-      for (int i = tid; i < n; i += blockDim.x) {
-        if (mask[i] && depth[i] >= min_depth) {
-          const unsigned u = __float_as_uint(depth[i]);
-          if ((u & hi_mask) == (prefix & hi_mask) && !((u >> b) & 1u)) ++c0;
-        }
-      }
-      atomicAdd(&s_cnt, c0);
-      __syncthreads();
-      const unsigned z = s_cnt;
-      if (rank >= z) {
-        rank -= z;
-        prefix |= 1u << b;
+  // usable depths are >= min_depth > 0: their bit patterns order like the values.  8-bit radix select, both order
+  // statistics at once: 4 passes over the image, a 256-bin LDS histogram per statistic and pass.
+  __shared__ unsigned s_hist[2][256];
+  __shared__ unsigned s_prefix[2], s_rank[2];
+  if (tid < 2) {
+    s_prefix[tid] = 0;
+    s_rank[tid] = tid == 0 ? (unsigned)((n_us - 1) / 2) : (unsigned)(n_us / 2);
+  }
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 512; i += blockDim.x) s_hist[i >> 8][i & 255] = 0;
+    __syncthreads();
+    const unsigned p0 = s_prefix[0], p1 = s_prefix[1];
+    const unsigned hi_mask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+    for (int i = tid; i < n; i += blockDim.x) {
+      if (mask[i] && depth[i] >= min_depth) {
+        const unsigned u = __float_as_uint(depth[i]);
+        const unsigned d = (u >> shift) & 255u;
+        if ((u & hi_mask) == (p0 & hi_mask)) atomicAdd(&s_hist[0][d], 1u);
+        if ((u & hi_mask) == (p1 & hi_mask)) atomicAdd(&s_hist[1][d], 1u);
       }
     }
-    vals[k] = __uint_as_float(prefix);
+    __syncthreads();
+    if (tid < 2) {
+      unsigned r = s_rank[tid], cum = 0;
+      int d = 0;
+      for (; d < 256; ++d) {
+        const unsigned c = s_hist[tid][d];
+        if (r < cum + c) break;
+        cum += c;
+      }
+      s_rank[tid] = r - cum;
+      s_prefix[tid] |= (unsigned)d << shift;
+    }
+    __syncthreads();
   }
+  float vals[2] = {__uint_as_float(s_prefix[0]), __uint_as_float(s_prefix[1])};
   if (tid == 0) *median = __fmul_rn(__fadd_rn(vals[0], vals[1]), 0.5f);
 }
 

@@ -172,6 +172,9 @@ class FoundationPose:
     self.H, self.W = depth.shape[:2]
     self.K, self.ob_id, self.ob_mask = K, ob_id, ob_mask
     hyp = self.generate_random_pose_hypo(K=K, rgb=rgb, depth=depth, mask=ob_mask, stats=stats)
+    # the colour image goes up once, in its own dtype (uint8: 0.9 MB), and is widened on the device; refiner and scorer
+    # both read that tensor
+    rgb = torch.as_tensor(np.ascontiguousarray(rgb) if isinstance(rgb, np.ndarray) else rgb, device='cuda').to(torch.float)
     refined, scores = self._refine_and_score(K, rgb, depth, U.depth2xyzmap(depth, K), hyp, iteration)
     order = torch.as_tensor(scores).argsort(descending=True)
     self.poses, self.scores = refined[order], scores[order]
@@ -185,6 +188,7 @@ class FoundationPose:
       logging.info("Please init pose by register first")
       raise RuntimeError
     depth = torch.as_tensor(depth, device='cuda', dtype=torch.float)
+    rgb = torch.as_tensor(np.ascontiguousarray(rgb) if isinstance(rgb, np.ndarray) else rgb, device='cuda').to(torch.float)
     depth = U.bilateral_filter_depth(U.erode_depth(depth, radius=2, device='cuda'), radius=2, device='cuda')
     xyz_map = U.depth2xyzmap_batch(depth[None], torch.as_tensor(K, dtype=torch.float, device='cuda')[None], zfar=np.inf)[0]
     pose, vis = self.refiner.predict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K,
