@@ -38,7 +38,7 @@ __device__ __forceinline__ void glds16c(const f16 *g, f16 *l) {
 // One workgroup tile: 64 NT pixels x BM couts, 4 waves as 2 (cout halves) x 2 (pixel halves), each wave (BM/2) x 32 NT.
 // NT = 4 -> the 256-pixel main tiles, NT = 1 -> 64-pixel tail tiles (conv_igemm2_kernel).  The accumulation order of an
 // output element does not depend on NT.
-template <int BM, int KW, bool CIN8, int NT>
+template <int BM, int KW, bool CIN8, int NT, bool RES>
 __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__restrict__ zero_page, const int m0, const int c0, f16 *smem) {
   constexpr int TN = 64 * NT;                              // pixels per workgroup
   constexpr int XH = TN * C2_BK, WH = BM * C2_BK;          // halfs per stage
@@ -135,13 +135,21 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
     }
   }
 
+  // accumulators start at the bias (fp32): a lane owns channels wm*WM + i*32 + rg*8 + lh*4 + (0..3) of its pixels
   floatx16 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int rg = 0; rg < 4; ++rg) {
+      const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      for (int j = 0; j < NT; ++j) {
+        acc[i][j][rg * 4 + 0] = bv.x;
+        acc[i][j][rg * 4 + 1] = bv.y;
+        acc[i][j][rg * 4 + 2] = bv.z;
+        acc[i][j][rg * 4 + 3] = bv.w;
+      }
+    }
 
   const int nk = p.Kpad / C2_BK;
   // 3-deep LDS-DMA ring: K-steps kt+1 and kt+2 stay in flight across the barrier (counted vmcnt + raw s_barrier;
@@ -182,37 +190,35 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
     }
   }
 
-  // ---- epilogue, fp16 NHWC: residual staged through LDS, fp32 math, LDS transpose, 16-byte row stores ----
+  // ---- epilogue, fp16 NHWC: residual staged through LDS, fp32 math, LDS transpose, 16-byte row stores.  RES is a
+  // compile-time flag, ReLU a branch-free max against 0 or -inf, the residual tile is requested in ONE batch before the
+  // barrier (the main loop's fragment registers are dead) - the K loop of a Linear layer is only 16 steps long, so this
+  // epilogue weighs as much as the loop itself ----
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   if (p.out_mode == 0) {
-    __syncthreads();
     f16 *stage = smem;
     constexpr int CPR = BM / 8;           // 16-byte chunks per staged row
     constexpr int NCH = TN * CPR / 256;
     constexpr int RB = NCH < 8 ? NCH : 8;
-    if (p.res) {
+    u32x4 rv[NCH];
+    if constexpr (RES) {
 #pragma unroll
-      for (int i0 = 0; i0 < NCH; i0 += RB) {
-        uint4 rv[RB];
+      for (int u = 0; u < NCH; ++u) {
+        const int idx = tid + 256 * u, px = idx / CPR, c16 = idx % CPR;
+        const int m = min(m0 + px, p.M - 1);    // unconditional (clamped) load: a guarded one makes hipcc wait per element
+        rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
+      }
+    }
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    __syncthreads();
+    if constexpr (RES) {
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-          const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
-          const int m = min(m0 + px, p.M - 1);    // unconditional (clamped) load: a guarded one makes hipcc wait per element
-          rv[u] = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < RB; ++u) {
-          const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
-          *reinterpret_cast<uint4 *>(&stage[px * SLD + c16 * 8]) = rv[u];
-        }
+      for (int u = 0; u < NCH; ++u) {
+        const int idx = tid + 256 * u, px = idx / CPR, c16 = idx % CPR;
+        *reinterpret_cast<u32x4 *>(&stage[px * SLD + c16 * 8]) = rv[u];
       }
       __syncthreads();
     }
-    // bias / positional-embedding values fetched in batches before use (see conv_halo.hip)
-    float4 bvs[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) bvs[i][rg] = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int pxl = wn * (32 * NT) + j * 32 + lr;
@@ -225,24 +231,25 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
           for (int rg = 0; rg < 4; ++rg)
             pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
       }
+      half4 rq[MT][4];
+      if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) rq[i][rg] = *reinterpret_cast<const half4 *>(&stage[pxl * SLD + wm * WM + i * 32 + rg * 8 + lh * 4]);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int col = wm * WM + i * 32 + rg * 8 + lh * 4;
-          const float4 bv = bvs[i][rg];
-          float v[4] = {acc[i][j][rg * 4 + 0] + bv.x, acc[i][j][rg * 4 + 1] + bv.y, acc[i][j][rg * 4 + 2] + bv.z,
-                        acc[i][j][rg * 4 + 3] + bv.w};
-          f16 *sp = &stage[pxl * SLD + col];
-          if (p.res) {
-            half4 rv = *reinterpret_cast<const half4 *>(sp);
+          float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
+          if constexpr (RES) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][rg][e];
           }
-          if (p.relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
           if (p.post_add) {
             const float4 pv = pvs[i][rg];
             v[0] += pv.x;
@@ -253,7 +260,7 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
           half4 hv;
 #pragma unroll
           for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
-          *reinterpret_cast<half4 *>(sp) = hv;
+          *reinterpret_cast<half4 *>(&stage[pxl * SLD + col]) = hv;
         }
       }
     }
@@ -282,11 +289,6 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
   }
 
   // ---- epilogue, other output modes (fp32 NHWC, transposed V): direct stores ----
-  float4 bvd[MT][4];     // bias fetched once, before use (a load inside the loops is waited for with vmcnt(0) each time)
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) bvd[i][rg] = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int m = m0 + wn * (32 * NT) + j * 32 + lr;
@@ -307,11 +309,10 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
       for (int rg = 0; rg < 4; ++rg) {
         const int co = c0 + wm * WM + i * 32 + rg * 8 + lh * 4;
         float v[4];
-        const float4 bv = bvd[i][rg];
-        v[0] = acc[i][j][rg * 4 + 0] + bv.x;
-        v[1] = acc[i][j][rg * 4 + 1] + bv.y;
-        v[2] = acc[i][j][rg * 4 + 2] + bv.z;
-        v[3] = acc[i][j][rg * 4 + 3] + bv.w;
+        v[0] = acc[i][j][rg * 4 + 0];      // the bias is already in the accumulator
+        v[1] = acc[i][j][rg * 4 + 1];
+        v[2] = acc[i][j][rg * 4 + 2];
+        v[3] = acc[i][j][rg * 4 + 3];
         if (p.res) {
           half4 rv = *reinterpret_cast<const half4 *>(p.res + (size_t)m * p.Cout + co);
 #pragma unroll
@@ -349,26 +350,26 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
 
 // Grid = n_main workgroups of 256 px x BM co, then n_tail4 workgroups of 64 px covering the LAST main-size tiles cut in four
 // (see conv3x3_halo kernels: at N=252 these layers have 1576 or 3150 tiles for 512 slots - a last round that is 8-15 % full).
-template <int BM, int KW, bool CIN8>
+template <int BM, int KW, bool CIN8, bool RES>
 __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f16 *__restrict__ zero_page, int n_main) {
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
   const int n_ct = p.Cout / BM;
   if ((int)blockIdx.x < n_main) {
     const int L = xcd_remap(blockIdx.x, n_main);
-    igemm2_tile<BM, KW, CIN8, 4>(p, zero_page, (L / n_ct) * C2_BN, (L % n_ct) * BM, smem);
+    igemm2_tile<BM, KW, CIN8, 4, RES>(p, zero_page, (L / n_ct) * C2_BN, (L % n_ct) * BM, smem);
   } else {
     const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
     const int L = n_main + (t >> 2);
     const int m0 = (L / n_ct) * C2_BN + (t & 3) * (C2_BN / 4);
     if (m0 >= p.M) return;
-    igemm2_tile<BM, KW, CIN8, 1>(p, zero_page, m0, (L % n_ct) * BM, smem);
+    igemm2_tile<BM, KW, CIN8, 1, RES>(p, zero_page, m0, (L % n_ct) * BM, smem);
   }
 }
 
 void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4);      // conv_halo.hip: main / quarter-tile split
 
-template <int BM, int KW, bool CIN8>
-static int launch_two(fp_ctx *ctx, const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
+template <int BM, int KW, bool CIN8, bool RES>
+static int launch_two_r(fp_ctx *ctx, const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
   const int n_tiles = ((a.M + C2_BN - 1) / C2_BN) * (a.Cout / BM);
   int n_main, n_tail4;
   halo_split(n_tiles, 2 * ctx->num_cu, &n_main, &n_tail4);
@@ -376,13 +377,19 @@ static int launch_two(fp_ctx *ctx, const ConvArgs &a, const f16 *zero_page, hipS
   constexpr int lds = main_b > epi_b ? main_b : epi_b;
   static bool attr_set = false;
   if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv_igemm2_kernel<BM, KW, CIN8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv_igemm2_kernel<BM, KW, CIN8, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   FP_REQUIRE(a.out_mode != 0 || (a.out_ld % 8 == 0 && a.coff_hi % 8 == 0), "conv: out_ld/coff must be multiples of 8 for fp16 output");
-  hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8>), dim3(n_main + n_tail4), dim3(256), lds, s, a, zero_page, n_main);
+  hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8, RES>), dim3(n_main + n_tail4), dim3(256), lds, s, a, zero_page, n_main);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
+}
+
+template <int BM, int KW, bool CIN8>
+static int launch_two(fp_ctx *ctx, const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
+  // the residual is added in the fp16-NHWC epilogue only; the other output modes read it directly
+  return (a.res && a.out_mode == 0) ? launch_two_r<BM, KW, CIN8, true>(ctx, a, zero_page, s) : launch_two_r<BM, KW, CIN8, false>(ctx, a, zero_page, s);
 }
 
 bool conv_halo_supported(const ConvArgs &a);
