@@ -28,6 +28,17 @@
 #define C2_BN 256
 #define C2_BK 32
 
+#ifdef HALO_STAMP
+// diagnostic build only (make -B EXTRA=-DHALO_STAMP): per-wave cycle counts of prologue / K loop / epilogue
+__device__ unsigned long long g_igemm_stamps[4096 * 4 * 4];
+extern "C" int fp_dbg_igemm_stamps(unsigned long long *host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm_stamps), sizeof(g_igemm_stamps)) == hipSuccess ? 0 : -1;
+}
+#define ISTAMP(x) x
+#else
+#define ISTAMP(x)
+#endif
+
 // LDS-DMA from inline asm (see conv_halo.hip: through the builtin hipcc turns every later LDS-read wait into lgkmcnt(0) and
 // every barrier into a full vmcnt(0) drain).  Completion is waited for by the explicit s_waitcnt vmcnt(n) before the barriers.
 __device__ __forceinline__ void glds16c(const f16 *g, f16 *l) {
@@ -43,6 +54,7 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
   constexpr int TN = 64 * NT;                              // pixels per workgroup
   constexpr int XH = TN * C2_BK, WH = BM * C2_BK;          // halfs per stage
   constexpr int SLD = BM + 8;                              // halfs per staged output row
+  ISTAMP(const unsigned long long t_entry = __builtin_amdgcn_s_memtime();)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   constexpr int WM = BM / 2, MT = WM / 32;
@@ -155,6 +167,7 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
   // 3-deep LDS-DMA ring: K-steps kt+1 and kt+2 stay in flight across the barrier (counted vmcnt + raw s_barrier;
   // a __syncthreads() would drain them).  Every wave issues exactly DMAW instructions per stage.
   constexpr int DMAW = NT + WQ;
+  ISTAMP(const unsigned long long t_loop = __builtin_amdgcn_s_memtime();)
   stage(0, 0);
   if (nk > 1) stage(1, 1);
   for (int kt = 0; kt < nk; ++kt) {
@@ -194,6 +207,7 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
   // compile-time flag, ReLU a branch-free max against 0 or -inf, the residual tile is requested in ONE batch before the
   // barrier (the main loop's fragment registers are dead) - the K loop of a Linear layer is only 16 steps long, so this
   // epilogue weighs as much as the loop itself ----
+  ISTAMP(const unsigned long long t_epi = __builtin_amdgcn_s_memtime();)
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   if (p.out_mode == 0) {
     f16 *stage = smem;
@@ -285,6 +299,7 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
         }
       }
     }
+    ISTAMP(if (lane == 0 && blockIdx.x < 4096) { unsigned long long *o = g_igemm_stamps + ((size_t)blockIdx.x * 4 + wave) * 4; o[0] = t_loop - t_entry; o[1] = t_epi - t_loop; o[2] = __builtin_amdgcn_s_memtime() - t_epi; o[3] = 1; })
     return;
   }
 

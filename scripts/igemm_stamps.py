@@ -1,0 +1,31 @@
+"""Diagnostic (needs `make -B EXTRA=-DHALO_STAMP`): per-wave cycle counts of conv_igemm2 (prologue / K loop / epilogue) for the
+Linear layer shapes; mean over the first workgroups."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from foundationpose_amd import _lib
+from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+
+ctx = _lib.Context.get('cuda:0')
+L = lib()
+for name, (M, K, N, use_res) in {'linear 512->512 +res': (100800, 512, 512, True), 'linear 512->512': (100800, 512, 512, False),
+                                  'linear 512->1024': (100800, 512, 1024, False)}.items():
+  g = torch.Generator(device='cuda').manual_seed(0)
+  x = torch.randn((M, 1, 1, K), device='cuda', generator=g).half()
+  w = (torch.randn((N, K), device='cuda', generator=g) * 0.05).half()
+  b = torch.randn((N,), device='cuda', generator=g) * 0.1
+  res = torch.randn((M, 1, 1, N), device='cuda', generator=g).half() if use_res else None
+  out = torch.empty((M, 1, 1, N), device='cuda', dtype=torch.float16)
+  run = lambda: check(L.fp_conv2d_f16(ctx.handle, ptr(x), M, 1, 1, K, ptr(w), ptr(b), N, 1, 1, 1, 0, ptr(res), 0, ptr(out), 0, stream_ptr()))
+  for _ in range(3): run()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(20): run()
+  e1.record(); torch.cuda.synchronize()
+  buf = np.zeros((4096, 4, 4), dtype=np.uint64)
+  L.fp_dbg_igemm_stamps(buf.ctypes.data_as(ctypes.c_void_p))
+  v = buf[:400].reshape(-1, 4).astype(np.float64)
+  v = v[v[:, 3] > 0]
+  m = v.mean(0)
+  print(f'{name:22s} {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us   prologue {m[0]:7.0f}  K loop {m[1]:7.0f}  epilogue {m[2]:7.0f} cycles')
