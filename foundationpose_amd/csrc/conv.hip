@@ -105,6 +105,9 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
     f16 *xs = smem + buf * (XH + WH), *ws = xs + XH;
     if (d < NT) {
       const int q = d;
+#ifdef IGEMM_SKIP_A
+      if (kt > 1) return;      // timing experiment only (wrong results): no activation DMA after the first two stages
+#endif
       if (lin) {
         glds16c(xlin[q] + kt * xlin_step[q], xs + (q * 4 + wave) * 512);
         return;
@@ -125,6 +128,9 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
       glds16c(src, xs + (q * 4 + wave) * 512);
     } else {
       const int q = d - NT;
+#ifdef IGEMM_SKIP_W
+      if (kt > 1) return;      // timing experiment only (wrong results): no weight DMA after the first two stages
+#endif
       glds16c(wsrc[q] + (size_t)kt * C2_BK, ws + (q * 4 + wave) * 512);
     }
   };
