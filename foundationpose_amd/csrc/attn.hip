@@ -31,7 +31,13 @@ __device__ __forceinline__ void at_glds16(const f16 *g, f16 *l) {
 __global__ void vt_pad_zero_kernel(f16 *__restrict__ vt, int rows, int T) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  for (int t = T; t < AT_TP; ++t) vt[(size_t)r * AT_TP + t] = (f16)0.f;
+  f16 *row = vt + (size_t)r * AT_TP;
+  if (T == 400) {                               // the network's case: 16 pad columns = two aligned 16-byte stores per row
+    *reinterpret_cast<uint4 *>(row + 400) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4 *>(row + 408) = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  for (int t = T; t < AT_TP; ++t) row[t] = (f16)0.f;
 }
 
 int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s) {
