@@ -41,6 +41,11 @@ extern "C" int fp_dbg_igemm_stamps(unsigned long long *host) {
 
 // LDS-DMA from inline asm (see conv_halo.hip: through the builtin hipcc turns every later LDS-read wait into lgkmcnt(0) and
 // every barrier into a full vmcnt(0) drain).  Completion is waited for by the explicit s_waitcnt vmcnt(n) before the barriers.
+// scalar base + 32-bit lane offset form: no per-lane 64-bit address arithmetic in front of the DMA
+__device__ __forceinline__ void glds16s(const f16 *sbase, unsigned voff_bytes, f16 *l) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)l);
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(sbase), "s"(la) : "memory");
+}
 __device__ __forceinline__ void glds16c(const f16 *g, f16 *l) {
   const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)l);
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");
@@ -80,25 +85,21 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
     xbase[q] = (long long)n * p.H * p.W * p.Cin;
     xch[q] = chp ^ ((px >> 2) & 3);                          // source chunk (swizzle on the SOURCE side)
   }
-  const f16 *wsrc[WQ];
-#pragma unroll
-  for (int q = 0; q < WQ; ++q) {
-    const int co = (q * 4 + wave) * 16 + (lane >> 2);
-    wsrc[q] = p.w + (size_t)(c0 + co) * p.Kpad + ((chp ^ ((co >> 2) & 3)) * 8);
-  }
+  // weights: instruction q of wave w covers couts (q*4 + w)*16 + lane/4; the swizzle term ((co>>2)&3) = (lane>>4)&3 does not
+  // depend on q, so ONE 32-bit lane offset serves every q and K-step, the rest of the address is scalar
+  const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + ((chp ^ ((lane >> 4) & 3)) * 8)) * 2);
+  const f16 *wbase = p.w + (size_t)c0 * p.Kpad;
   // DMA instruction d of a stage: d = 0..NT-1 the activation gather (pixel group d), d = NT.. the weights
-  // 1x1 (Linear) layers: a pixel's K-row is contiguous, the gather address of step kt is a fixed per-lane base + kt*64 B
-  // (pixels past M read the zero page with stride 0) - no per-step tap / bounds arithmetic in front of the DMA
-  const f16 *xlin[NT];
-  int xlin_step[NT];
-  const bool lin = KW == 1 && !CIN8 && p.stride == 1 && p.pad == 0;     // output pixel m reads input pixel m
+  // 1x1 (Linear) layers: a pixel's K-row is contiguous, the gather address of step kt is a fixed 32-bit lane offset from the
+  // scalar base p.in + kt*64 B - no per-step tap / bounds / 64-bit address arithmetic in front of the DMA
+  // (pixels past M are clamped to the last pixel: their products only reach output rows that are never stored)
+  unsigned xlin[NT];
+  const bool lin = KW == 1 && !CIN8 && p.stride == 1 && p.pad == 0 && (double)p.M * p.Cin * 2.0 < 4294967296.0;   // output pixel m reads input pixel m
   if (lin) {
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
-      const int m = m0 + (q * 4 + wave) * 16 + (lane >> 2);
-      const bool mv = m < p.M;
-      xlin[q] = mv ? p.in + (size_t)m * p.Cin + xch[q] * 8 : zero_page;
-      xlin_step[q] = mv ? C2_BK : 0;
+      const int m = min(m0 + (q * 4 + wave) * 16 + (lane >> 2), p.M - 1);
+      xlin[q] = (unsigned)(m * p.Cin + xch[q] * 8) * 2u;
     }
   }
   auto stage_one = [&](int kt, int buf, int d) __attribute__((always_inline)) {
@@ -109,7 +110,7 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
       if (kt > 1) return;      // timing experiment only (wrong results): no activation DMA after the first two stages
 #endif
       if (lin) {
-        glds16c(xlin[q] + kt * xlin_step[q], xs + (q * 4 + wave) * 512);
+        glds16s(p.in + kt * C2_BK, xlin[q], xs + (q * 4 + wave) * 512);
         return;
       }
       const int k = kt * C2_BK + xch[q] * 8;
@@ -131,7 +132,7 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
 #ifdef IGEMM_SKIP_W
       if (kt > 1) return;      // timing experiment only (wrong results): no weight DMA after the first two stages
 #endif
-      glds16c(wsrc[q] + (size_t)kt * C2_BK, ws + (q * 4 + wave) * 512);
+      glds16s(wbase + (size_t)(q * 64) * p.Kpad + (size_t)kt * C2_BK, woff, ws + (q * 4 + wave) * 512);
     }
   };
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
