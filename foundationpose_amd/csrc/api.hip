@@ -262,9 +262,10 @@ extern "C" int fp_render(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses,
   return launch_render(ctx, a, (hipStream_t)stream);
 }
 
-extern "C" int fp_render_net(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
-                             const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
-                             void *d_net_out, void *stream) {
+// vscratch: optional N * V * 16 bytes for the vertex pre-pass (nullptr: every triangle transforms its own vertices)
+static int render_net_impl(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+                           const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
+                           void *d_net_out, void *vscratch, void *stream) {
   FP_REQUIRE(ctx && d_net_out, "fp_render_net: null argument");
   RenderArgs a;
   FP_TRY(fill_render(a, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w));
@@ -275,7 +276,15 @@ extern "C" int fp_render_net(fp_ctx *ctx, const fp_mesh *mesh, const float *d_po
   a.mesh_diameter = (float)mesh_diameter;
   a.invalid_thres = invalid_thres;
   a.normalize_xyz = normalize_xyz;
+  a.vbuf = vscratch;
   return launch_render(ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int fp_render_net(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+                             const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
+                             void *d_net_out, void *stream) {
+  return render_net_impl(ctx, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w, mesh_diameter, normalize_xyz, invalid_thres, d_net_out,
+                         nullptr, stream);
 }
 
 extern "C" int fp_crop_observed(fp_ctx *ctx, const float *d_rgb, const float *d_geom, int H, int W, const double *K, const float *d_tf,
@@ -377,6 +386,20 @@ static bool same_render_key(const fp_object_batch &a, const fp_object_batch &b) 
   return a.mesh == b.mesh && a.H == b.H && a.W == b.W && a.mesh_diameter == b.mesh_diameter && memcmp(a.K, b.K, 9 * sizeof(double)) == 0;
 }
 
+// Scratch for the renderer's vertex pre-pass: 16 bytes per (hypothesis, vertex) over all objects, from the arena's slack if it
+// is there (nullptr otherwise: the renderer then transforms vertices per triangle - slower, same result).
+static char *take_vertex_scratch(fp_ctx *ctx, const fp_object_batch *objs, int n_obj) {
+  size_t bytes = 0;
+  int n = 0;
+  for (int o = 0; o < n_obj; ++o) {
+    bytes += (size_t)objs[o].n * (size_t)(objs[o].mesh ? objs[o].mesh->d.V : 0) * 16;
+    n += objs[o].n;
+  }
+  // the network pass that follows allocates fp_arena_inner_bytes(n) from the same arena: leave that room
+  if (bytes == 0 || ctx->arena.cap - ctx->arena.off < bytes + fp_arena_inner_bytes(n) + ((size_t)1 << 20)) return nullptr;
+  return (char *)ctx->arena.take(bytes);
+}
+
 static int count_runs(const fp_object_batch *objs, int n_obj) {
   int k = 0;
   for (int o = 0; o < n_obj;) {
@@ -409,7 +432,9 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
     TAKE(net_in, f16, (size_t)2 * N * img);
     float *tr = d_trans ? d_trans : trans, *ro = d_rot ? d_rot : rot;
     const int n_runs = count_runs(objs, n_obj);
+    char *vscratch = take_vertex_scratch(ctx, objs, n_obj);     // reused by every iteration
     for (int it = 0; it < iteration; ++it) {
+      size_t voff = 0;
       int off = 0, k = 0;
       StreamFanout fo(ctx, s, n_runs);
       for (int o = 0; o < n_obj;) {       // per run of like objects: crop windows + render (side A); per object: observed crop (side B)
@@ -420,8 +445,9 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
           hipStream_t so = fo.stream_for(k++);
           float *p = d_poses + (size_t)off * 16;
           FP_TRY(launch_crop_window_tf(p, cnt, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
-          FP_TRY(fp_render_net(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
-                               cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, so));
+          FP_TRY(render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
+                                 cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, vscratch ? vscratch + voff : nullptr, so));
+          voff += (size_t)cnt * ob.mesh->d.V * 16;
           for (int q = o; q < e; ++q) {
             const fp_object_batch &oq = objs[q];
             if (oq.n == 0) continue;
@@ -479,6 +505,8 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
     TAKE(bbox, float, (size_t)N * 4);
     TAKE(net_in, f16, (size_t)2 * N * img);
     int off = 0, k = 0;
+    char *vscratch = take_vertex_scratch(ctx, objs, n_obj);
+    size_t voff = 0;
     StreamFanout fo(ctx, s, count_runs(objs, n_obj));
     for (int o = 0; o < n_obj;) {
       int e = o + 1, cnt = objs[o].n;
@@ -488,8 +516,9 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
         hipStream_t so = fo.stream_for(k++);
         const float *p = d_poses + (size_t)off * 16;
         FP_TRY(launch_crop_window_tf(p, cnt, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
-        FP_TRY(fp_render_net(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
-                             net_in + (size_t)off * img, so));
+        FP_TRY(render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
+                               net_in + (size_t)off * img, vscratch ? vscratch + voff : nullptr, so));
+        voff += (size_t)cnt * ob.mesh->d.V * 16;
         for (int q = o; q < e; ++q) {
           const fp_object_batch &oq = objs[q];
           if (oq.n == 0) continue;

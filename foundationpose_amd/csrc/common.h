@@ -216,6 +216,7 @@ struct RenderArgs {
   f16 *net_out;                         // mode 1
   float mesh_diameter, invalid_thres;
   int normalize_xyz;
+  void *vbuf = nullptr;                 // optional scratch, N * V * 16 B: transformed vertices (render pre-pass)
 };
 int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s);
 int launch_crop_window_tf(const float *poses, int N, const double *K, double crop_ratio, double diameter, int ow, int oh, float *tf,

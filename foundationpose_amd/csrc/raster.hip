@@ -53,8 +53,59 @@ __device__ __forceinline__ Vtx xform_vertex(const float *__restrict__ pos, int v
   return o;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int strip_rows, int n_strips) {
+// clip matrix of hypothesis b in float64, rounded once (oracle/render.py: clip_matrices; src/Utils.py:155-181); one thread
+__device__ void clip_matrix(const RenderArgs &a, int b, const float *pose, float *sM) {
+  const double W = a.W, H = a.H, zn = 0.001, zf = 100.0;
+  double P[16] = {2 * a.K[0] / W, -2 * a.K[1] / W, (-2 * a.K[2] + W) / W, 0,
+                  0, 2 * a.K[4] / H, (2 * a.K[5] - H) / H, 0,
+                  0, 0, -(zf + zn) / (zf - zn), -2 * (zf * zn) / (zf - zn),
+                  0, 0, -1, 0};
+  double G[16];  // glcam_in_cvcam @ ob_in_cam : negate rows 1,2
+  for (int c = 0; c < 4; ++c) {
+    G[c] = pose[c];
+    G[4 + c] = -(double)pose[4 + c];
+    G[8 + c] = -(double)pose[8 + c];
+    G[12 + c] = pose[12 + c];
+  }
+  double Mx[16];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += P[r * 4 + k] * G[k * 4 + c];
+      Mx[r * 4 + c] = s;
+    }
+  if (a.bbox2d) {
+    const float *bb = a.bbox2d + (size_t)b * 4;
+    double l = bb[0], t = H - (double)bb[1], r = bb[2], bt = H - (double)bb[3];
+    double t00 = W / (r - l), t11 = H / (t - bt), t30 = (W - r - l) / (r - l), t31 = (H - t - bt) / (t - bt);
+    for (int c = 0; c < 4; ++c) {
+      double r3 = Mx[12 + c];
+      Mx[c] = t00 * Mx[c] + t30 * r3;
+      Mx[4 + c] = t11 * Mx[4 + c] + t31 * r3;
+    }
+  }
+  for (int i = 0; i < 16; ++i) sM[i] = (float)Mx[i];
+}
+
+// Vertex pre-pass for the fused network path: every hypothesis' vertices transformed ONCE (the triangle loop of render_kernel
+// otherwise re-transforms a vertex for each of its ~6 triangles, in each strip, behind two dependent global round trips).
+// One int4 per vertex: X (INT_MIN = behind the camera / off range), Y, bits of z/w, bits of w - exactly xform_vertex's values.
+__global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 *__restrict__ vout) {
+  __shared__ float sM[16];
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) clip_matrix(a, b, a.poses + (size_t)b * 16, sM);
+  __syncthreads();
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= a.mesh.V) return;
+  float M[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) M[i] = sM[i];
+  const Vtx o = xform_vertex(a.mesh.pos, v, M, 0.5f * (float)a.Wo, 0.5f * (float)a.Ho);
+  vout[(size_t)b * a.mesh.V + v] = make_int4(o.ok ? o.X : (int)0x80000000, o.Y, __float_as_int(o.zn), __float_as_int(o.w));
+}
+
+template <int MODE, bool VB>
+__global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int strip_rows, int n_strips, const int4 *__restrict__ vbuf) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];
   __shared__ float sM[16];
   __shared__ float sP[12];
@@ -66,37 +117,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   const float *pose = a.poses + (size_t)b * 16;
 
   if (threadIdx.x == 0) {
-    // clip matrix in float64, rounded once (oracle/render.py: clip_matrices; src/Utils.py:155-181)
-    const double W = a.W, H = a.H, zn = 0.001, zf = 100.0;
-    double P[16] = {2 * a.K[0] / W, -2 * a.K[1] / W, (-2 * a.K[2] + W) / W, 0,
-                    0, 2 * a.K[4] / H, (2 * a.K[5] - H) / H, 0,
-                    0, 0, -(zf + zn) / (zf - zn), -2 * (zf * zn) / (zf - zn),
-                    0, 0, -1, 0};
-    double G[16];  // glcam_in_cvcam @ ob_in_cam : negate rows 1,2
-    for (int c = 0; c < 4; ++c) {
-      G[c] = pose[c];
-      G[4 + c] = -(double)pose[4 + c];
-      G[8 + c] = -(double)pose[8 + c];
-      G[12 + c] = pose[12 + c];
-    }
-    double Mx[16];
-    for (int r = 0; r < 4; ++r)
-      for (int c = 0; c < 4; ++c) {
-        double s = 0;
-        for (int k = 0; k < 4; ++k) s += P[r * 4 + k] * G[k * 4 + c];
-        Mx[r * 4 + c] = s;
-      }
-    if (a.bbox2d) {
-      const float *bb = a.bbox2d + (size_t)b * 4;
-      double l = bb[0], t = H - (double)bb[1], r = bb[2], bt = H - (double)bb[3];
-      double t00 = W / (r - l), t11 = H / (t - bt), t30 = (W - r - l) / (r - l), t31 = (H - t - bt) / (t - bt);
-      for (int c = 0; c < 4; ++c) {
-        double r3 = Mx[12 + c];
-        Mx[c] = t00 * Mx[c] + t30 * r3;
-        Mx[4 + c] = t11 * Mx[4 + c] + t31 * r3;
-      }
-    }
-    for (int i = 0; i < 16; ++i) sM[i] = (float)Mx[i];
+    clip_matrix(a, b, pose, sM);
     for (int i = 0; i < 12; ++i) sP[i] = pose[i];
   }
   for (int i = threadIdx.x; i < npix; i += RB_THREADS) zbuf[i] = ~0ull;
@@ -107,13 +128,23 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   for (int i = 0; i < 16; ++i) M[i] = sM[i];
   const float hw = 0.5f * (float)Wo, hh = 0.5f * (float)Ho;
   const MeshDev &m = a.mesh;
+  const int4 *vb = VB ? vbuf + (size_t)b * m.V : nullptr;
+  auto vertex = [&](int i) -> Vtx {          // with the pre-pass: one 16-byte load instead of 3 loads + the transform
+    if (!VB) return xform_vertex(m.pos, i, M, hw, hh);
+    const int4 q = vb[i];
+    Vtx o;
+    o.X = q.x;
+    o.Y = q.y;
+    o.zn = __int_as_float(q.z);
+    o.w = __int_as_float(q.w);
+    o.ok = q.x != (int)0x80000000;
+    return o;
+  };
 
   // ---- pass 1: stream triangles, resolve visibility in LDS ----
   for (int t = threadIdx.x; t < m.F; t += RB_THREADS) {
     int i0 = m.faces[t * 3], i1 = m.faces[t * 3 + 1], i2 = m.faces[t * 3 + 2];
-    Vtx v0 = xform_vertex(m.pos, i0, M, hw, hh);
-    Vtx v1 = xform_vertex(m.pos, i1, M, hw, hh);
-    Vtx v2 = xform_vertex(m.pos, i2, M, hw, hh);
+    Vtx v0 = vertex(i0), v1 = vertex(i1), v2 = vertex(i2);
     if (!(v0.ok && v1.ok && v2.ok)) continue;
     // Triangles whose snapped coordinates stay within +-1024 px (all but the ones far outside the crop) take the same
     // integer edge functions in 32-bit arithmetic: |X|,|Y| < 2^14 -> differences < 2^15, products < 2^30, sums < 2^31.
@@ -208,9 +239,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     if (key != ~0ull) {
       int t = (int)(unsigned)(key & 0xffffffffull);
       int i0 = m.faces[t * 3], i1 = m.faces[t * 3 + 1], i2 = m.faces[t * 3 + 2];
-      Vtx v0 = xform_vertex(m.pos, i0, M, hw, hh);
-      Vtx v1 = xform_vertex(m.pos, i1, M, hw, hh);
-      Vtx v2 = xform_vertex(m.pos, i2, M, hw, hh);
+      Vtx v0 = vertex(i0), v1 = vertex(i1), v2 = vertex(i2);
       float fa, b0, b1, b2;
       const int amax = max(max(max(abs(v0.X), abs(v0.Y)), max(abs(v1.X), abs(v1.Y))), max(abs(v2.X), abs(v2.Y)));
       if (amax < 16384) {                         // the same integers in 32-bit arithmetic (see pass 1)
@@ -355,13 +384,18 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s) {
   size_t lds = (size_t)strip_rows * a.Wo * 8;
   dim3 grid((unsigned)(a.N * n_strips));
   ProfScope ps(ctx, s, "render", 0);
-  if (a.net_out) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)render_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(render_kernel<1>, grid, dim3(RB_THREADS), lds, s, a, strip_rows, n_strips);
-  } else {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)render_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(render_kernel<0>, grid, dim3(RB_THREADS), lds, s, a, strip_rows, n_strips);
+  const int4 *vbuf = (const int4 *)a.vbuf;
+  if (vbuf) {
+    hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, (int4 *)a.vbuf);
+    FP_CHECK_HIP(hipGetLastError());
   }
+  auto go = [&](auto kern) -> int {
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(RB_THREADS), lds, s, a, strip_rows, n_strips, vbuf);
+    return FP_OK;
+  };
+  if (a.net_out) FP_TRY(vbuf ? go(render_kernel<1, true>) : go(render_kernel<1, false>));
+  else FP_TRY(vbuf ? go(render_kernel<0, true>) : go(render_kernel<0, false>));
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
