@@ -29,14 +29,23 @@ __device__ __forceinline__ float frame_at(const float *img, int H, int W, int C,
 __global__ __launch_bounds__(256) void crop_observed_kernel(CropArgs a) {
   const int b = blockIdx.y;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.Ho * a.Wo) return;
-  const int j = p / a.Wo, i = p - j * a.Wo;
   const float *T = a.tf + (size_t)b * 9;
   const float *pose = a.poses + (size_t)b * 16;
-  const double sx = T[0], tx = T[2], sy = T[4], ty = T[5];
   const int H = a.H, W = a.W;
-  const double ax = (1.0 / sx) * W / (W - 1.0), bx = (-tx / sx) * W / (W - 1.0) - 0.5;
-  const double ay = (1.0 / sy) * H / (H - 1.0), by = (-ty / sy) * H / (H - 1.0) - 0.5;
+  // the per-hypothesis affine coefficients (eight float64 divisions) once per workgroup, not once per pixel
+  __shared__ double s_aff[4];
+  if (threadIdx.x == 0) {
+    const double sx0 = T[0], tx0 = T[2], sy0 = T[4], ty0 = T[5];
+    s_aff[0] = (1.0 / sx0) * W / (W - 1.0);
+    s_aff[1] = (-tx0 / sx0) * W / (W - 1.0) - 0.5;
+    s_aff[2] = (1.0 / sy0) * H / (H - 1.0);
+    s_aff[3] = (-ty0 / sy0) * H / (H - 1.0) - 0.5;
+  }
+  __syncthreads();
+  if (p >= a.Ho * a.Wo) return;
+  const int j = p / a.Wo, i = p - j * a.Wo;
+  const double sx = T[0], tx = T[2], sy = T[4], ty = T[5];
+  const double ax = s_aff[0], bx = s_aff[1], ay = s_aff[2], by = s_aff[3];
   const double xd = ax * i + bx, yd = ay * j + by;
   const float x = (float)xd, y = (float)yd;
 
