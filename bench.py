@@ -207,7 +207,7 @@ def main():
                              '480x640 RGB-D frame; one such object per GPU, hypotheses sharded over all ranks',
                  'hypotheses_per_object': N_HYP, 'objects': world, 'est_refine_iter': ITER, 'parallelism': f'hyp-shard x{world}',
                  'weights': 'seeded random (reference state_dict layout)'},
-      'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_halo_kernel (3x3 stride-1 convolutions: 93 % of the conv FLOPs)',
+      'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_halo_dma_kernel (3x3 stride-1 convolutions: 93 % of the conv FLOPs)',
                    'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F16_TFLOPS,
                    'avg_launch_ms': conv['total_ms'] / max(conv['launches'], 1), 'launches': conv['launches'],
                    'flops_per_launch': conv['flops'] / max(conv['launches'], 1),
