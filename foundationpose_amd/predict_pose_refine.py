@@ -13,6 +13,57 @@ from . import _lib
 from ._lib import FP_NET_REFINE, FpRefineCfg, byref, check, k_ptr, lib, ptr, stream_ptr
 from .Utils import _ctx_of, make_mesh_tensors
 from .config import Cfg, load_run_dir
+from .pose_dataset import BatchPoseData, planar_views
+
+
+def crop_net_input(ctx, dm, poses, rgb_t, geom_t, K, crop_ratio, mesh_diameter, normalize_xyz, mode, render_size=(160, 160)):
+  """Crop window -> render (side A) -> observed crop (side B) into one fp16 net tensor, three launches on the current
+  stream: the steps fp_refine_predict / fp_score_predict_features run internally, exposed one at a time.
+  mode 0: geom = xyz_map (refiner, invalid below 1 mm); mode 1: geom = depth (scorer, invalid below 0.1 m).
+  Returns (net (2N,h,w,8) fp16, tf_to_crops (N,3,3), bbox2d (N,4))."""
+  dev = poses.device
+  N = len(poses)
+  H, W = rgb_t.shape[:2]
+  h, w = int(render_size[0]), int(render_size[1])
+  tf = torch.empty((N, 3, 3), device=dev, dtype=torch.float)
+  bbox = torch.empty((N, 4), device=dev, dtype=torch.float)
+  net = torch.empty((2 * N, h, w, 8), device=dev, dtype=torch.float16)
+  Kd, Kp = k_ptr(K)
+  s = stream_ptr(dev)
+  nz = 1 if normalize_xyz else 0
+  check(lib().fp_crop_window_tf(ctx.handle, ptr(poses), N, Kp, float(crop_ratio), float(mesh_diameter), w, h, ptr(tf), ptr(bbox), s))
+  check(lib().fp_render_net(ctx.handle, dm.handle, ptr(poses), N, Kp, H, W, ptr(bbox), h, w, float(mesh_diameter), nz,
+                            0.1 if mode else 0.001, ptr(net), s))
+  check(lib().fp_crop_observed(ctx.handle, ptr(rgb_t), ptr(geom_t), H, W, Kp, ptr(tf), ptr(poses), N, h, w, mode, float(mesh_diameter),
+                               nz, 1, ptr(net[N:]), s))
+  return net, tf, bbox
+
+
+@torch.inference_mode()
+def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_ratio, xyz_map, normal_map=None, mesh_diameter=None, cfg=None,
+                         glctx=None, mesh_tensors=None, dataset=None):
+  """predict_pose_refine.py:24-89 including dataset.transform_batch (h5_dataset.py:79-127): the batch one refinement
+  iteration feeds to RefineNet.  `pose_data.net_input` is what the HIP network reads; rgbAs / xyz_mapAs / rgbBs /
+  xyz_mapBs are its float32 planar views (fp16 precision).  `dataset` is accepted and ignored: its transform is fused
+  into the kernels."""
+  cfg = cfg if cfg is not None else {}
+  if cfg.get('use_normal', False) or normal_map is not None:
+    raise NotImplementedError('use_normal=True is not implemented (no released model uses it)')
+  ctx = _ctx_of(glctx)
+  dev = torch.device('cuda', ctx.device_index)
+  if mesh_tensors is None:
+    mesh_tensors = make_mesh_tensors(mesh, device=dev)
+  dm = _lib.device_mesh(ctx, mesh_tensors)
+  poses = torch.as_tensor(ob_in_cams, device=dev, dtype=torch.float).reshape(-1, 4, 4).contiguous()
+  rgb_t = torch.as_tensor(rgb, device=dev, dtype=torch.float).contiguous()
+  xyz_t = torch.as_tensor(xyz_map, device=dev, dtype=torch.float).contiguous()
+  assert xyz_t.shape[:2] == rgb_t.shape[:2] == tuple(depth.shape[:2])
+  net, tf, _ = crop_net_input(ctx, dm, poses, rgb_t, xyz_t, K, crop_ratio, mesh_diameter, cfg.get('normalize_xyz', False), 0, render_size)
+  rgbAs, xyz_mapAs, rgbBs, xyz_mapBs = planar_views(net)
+  N = len(poses)
+  Ks = torch.as_tensor(np.asarray(K), dtype=torch.float, device=dev).reshape(1, 3, 3).expand(N, 3, 3)
+  return BatchPoseData(rgbAs=rgbAs, rgbBs=rgbBs, xyz_mapAs=xyz_mapAs, xyz_mapBs=xyz_mapBs, poseA=poses, tf_to_crops=tf, Ks=Ks,
+                       mesh_diameters=torch.full((N,), float(mesh_diameter), device=dev), net_input=net)
 
 
 class PoseRefinePredictor:
@@ -70,6 +121,29 @@ class PoseRefinePredictor:
       c.trans_normalizer[i] = tn[i]
     c.rot_normalizer = float(self.cfg['rot_normalizer'])
     return c
+
+  @torch.inference_mode()
+  def forward(self, pose_data):
+    """RefineNet on a batch made by make_crop_data_batch (predict_pose_refine.py:186-193, `self.model(A, B)`):
+    returns dict(trans (N,3), rot (N,3|6)) of raw head outputs."""
+    net = pose_data.net_input
+    N = len(net) // 2
+    trans = torch.empty((N, 3), device=net.device, dtype=torch.float)
+    rot = torch.empty((N, self.model.rot_dim), device=net.device, dtype=torch.float)
+    check(lib().fp_refine_forward(self.ctx.handle, self.model.handle, ptr(net), N, ptr(trans), ptr(rot), stream_ptr(net.device)))
+    return dict(trans=trans, rot=rot)
+
+  @torch.inference_mode()
+  def update_poses(self, poseA, trans, rot, mesh_diameter):
+    """predict_pose_refine.py:195-231: head outputs -> B_in_cam (egocentric delta applied to poseA)."""
+    c = self._c_cfg()
+    poseA = poseA.contiguous()
+    out = torch.empty_like(poseA)
+    tn = np.array([c.trans_normalizer[i] for i in range(3)], dtype=np.float32)
+    scale = float(mesh_diameter) / 2 if c.normalize_xyz else 1.0
+    check(lib().fp_pose_update(self.ctx.handle, ptr(poseA), ptr(trans), ptr(rot), len(poseA), self.model.rot_dim, c.trans_rep_tanh,
+                               tn.ctypes.data, c.rot_normalizer, scale, ptr(out), stream_ptr(poseA.device)))
+    return out
 
   @torch.inference_mode()
   def predict_multi(self, objects, iteration=5):

@@ -8,6 +8,46 @@ from . import _lib
 from ._lib import FP_NET_SCORE, check, k_ptr, lib, ptr, stream_ptr
 from .Utils import _ctx_of, make_mesh_tensors
 from .config import Cfg, load_run_dir
+from .pose_dataset import BatchPoseData, planar_views
+from .predict_pose_refine import crop_net_input
+
+
+@torch.inference_mode()
+def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_ratio, normal_map=None, mesh_diameter=None, glctx=None,
+                         mesh_tensors=None, dataset=None, cfg=None):
+  """predict_score.py:56-114 including dataset.transform_batch (h5_dataset.py:137-179): the batch ScoreNet reads.
+  Side B's xyz comes from the cropped depth through the full-resolution round trip of h5_dataset.py:158-161, composed
+  per pixel inside fp_crop_observed.  depthAs / depthBs are float32 (render depth; nearest crop of `depth`)."""
+  cfg = cfg if cfg is not None else {}
+  if cfg.get('use_normal', False) or normal_map is not None:
+    raise NotImplementedError('use_normal=True is not implemented (no released model uses it)')
+  ctx = _ctx_of(glctx)
+  dev = torch.device('cuda', ctx.device_index)
+  if mesh_tensors is None:
+    mesh_tensors = make_mesh_tensors(mesh, device=dev)
+  dm = _lib.device_mesh(ctx, mesh_tensors)
+  poses = torch.as_tensor(ob_in_cams, device=dev, dtype=torch.float).reshape(-1, 4, 4).contiguous()
+  rgb_t = torch.as_tensor(rgb, device=dev, dtype=torch.float).contiguous()
+  depth_t = torch.as_tensor(depth, device=dev, dtype=torch.float).contiguous()
+  H, W = depth_t.shape[:2]
+  net, tf, bbox = crop_net_input(ctx, dm, poses, rgb_t, depth_t, K, crop_ratio, mesh_diameter, cfg.get('normalize_xyz', False), 1, render_size)
+  rgbAs, xyz_mapAs, rgbBs, xyz_mapBs = planar_views(net)
+  N = len(poses)
+  h, w = int(render_size[0]), int(render_size[1])
+  Kd, Kp = k_ptr(K)
+  s = stream_ptr(dev)
+  depthAs = torch.empty((N, 1, h, w), device=dev, dtype=torch.float)
+  check(lib().fp_render(ctx.handle, dm.handle, ptr(poses), N, Kp, H, W, ptr(bbox), h, w, 1, 0.8, 0.5, None, ptr(depthAs), None, None, s))
+  # depthBs: the nearest-sampled crop alone = the refiner-mode kernel on (0,0,depth) with nothing to centre on
+  zmap = torch.zeros((H, W, 3), device=dev, dtype=torch.float)
+  zmap[..., 2] = depth_t
+  origin = torch.zeros((N, 4, 4), device=dev, dtype=torch.float)
+  raw = torch.empty((N, 6, h, w), device=dev, dtype=torch.float)
+  check(lib().fp_crop_observed(ctx.handle, ptr(rgb_t), ptr(zmap), H, W, Kp, ptr(tf), ptr(origin), N, h, w, 0, float(mesh_diameter), 0, 0,
+                               ptr(raw), s))
+  Ks = torch.as_tensor(np.asarray(K), dtype=torch.float, device=dev).reshape(1, 3, 3).expand(N, 3, 3)
+  return BatchPoseData(rgbAs=rgbAs, rgbBs=rgbBs, depthAs=depthAs, depthBs=raw[:, 5:6], xyz_mapAs=xyz_mapAs, xyz_mapBs=xyz_mapBs, poseA=poses,
+                       tf_to_crops=tf, Ks=Ks, mesh_diameters=torch.full((N,), float(mesh_diameter), device=dev), net_input=net)
 
 
 class ScorePredictor:
@@ -59,6 +99,15 @@ class ScorePredictor:
     check(lib().fp_score_predict_features(ctx.handle, self.model.handle, dm.handle, ptr(rgb_t), ptr(depth_t), H, W, Kp,
                                           float(mesh_diameter), float(self.cfg['crop_ratio']), 1 if self.cfg['normalize_xyz'] else 0,
                                           ptr(poses), N, ptr(feats), stream_ptr(dev)))
+    return feats
+
+  @torch.inference_mode()
+  def forward_features(self, pose_data):
+    """ScoreNetMultiPair.extract_feat on a batch made by make_crop_data_batch (score_network.py:57-80) -> (N,512)."""
+    net = pose_data.net_input
+    N = len(net) // 2
+    feats = torch.empty((N, 512), dtype=torch.float, device=net.device)
+    check(lib().fp_score_features(self.ctx.handle, self.model.handle, ptr(net), N, ptr(feats), stream_ptr(net.device)))
     return feats
 
   @torch.inference_mode()

@@ -149,6 +149,64 @@ def test_fused_crop_tensors_match_oracle(sc, fp, which):
   assert float((B_ref[:, 3:] != 0).float().mean()) > 0.05     # the observed object is inside the crops
 
 
+@pytest.mark.parametrize('which', ['refine', 'score'])
+def test_make_crop_data_batch_api(sc, fp, which):
+  """The reference's intermediate API (predict_pose_refine.py:24-89, predict_score.py:56-114): make_crop_data_batch ->
+  BatchPoseData.  Planar fields are views of the fp16 net tensor -> atol 1.5e-3 with the nearest-sampling allowance of
+  the test above; tf_to_crops, depthBs bit-exact (same float32 op order / a copy of source pixels); depthAs to float32
+  rounding.  Then: the step-by-step loop through this API is the fused C call, bit for bit."""
+  from oracle import geometry as G, predict as OP
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.config import REFINE_DEFAULT, SCORE_DEFAULT
+  n = 8
+  poses = util.hypotheses(sc, n, jitter_seed=7)
+  depth = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+  rgb_t = torch.as_tensor(sc['rgb'], dtype=torch.float32)
+  mt = util.to_dev(sc['mt'])
+  if which == 'refine':
+    from foundationpose_amd.predict_pose_refine import PoseRefinePredictor, make_crop_data_batch
+    cfg = dict(OP.DEFAULT_REFINE_CFG)
+    xyz_map = G.depth2xyzmap(depth, sc['K'])
+    ref = OP.make_crop_data_batch_refine(cfg, poses, sc['mt'], rgb_t, torch.from_numpy(depth), sc['K'], torch.from_numpy(xyz_map), sc['diameter'])
+    pd = make_crop_data_batch((160, 160), poses, None, sc['rgb'], depth, sc['K'], cfg['crop_ratio'], xyz_map, mesh_diameter=sc['diameter'],
+                              cfg=cfg, mesh_tensors=mt)
+  else:
+    from foundationpose_amd.predict_score import ScorePredictor, make_crop_data_batch
+    cfg = dict(OP.DEFAULT_SCORE_CFG)
+    ref = OP.make_crop_data_batch_score(cfg, poses, sc['mt'], rgb_t, torch.from_numpy(depth), sc['K'], sc['diameter'])
+    pd = make_crop_data_batch((160, 160), poses, None, sc['rgb'], depth, sc['K'], cfg['crop_ratio'], mesh_diameter=sc['diameter'],
+                              cfg=cfg, mesh_tensors=mt)
+  assert len(pd) == n and pd.net_input.shape == (2 * n, 160, 160, 8) and pd.normalAs is None and pd.poseB is None
+  np.testing.assert_array_equal(pd.tf_to_crops.cpu().numpy(), ref['tf_to_crops'].numpy())
+  np.testing.assert_array_equal(pd.poseA.cpu().numpy(), poses)
+  np.testing.assert_array_equal(pd.Ks.cpu().numpy(), np.broadcast_to(sc['K'].astype(np.float32), (n, 3, 3)))
+  assert float((pd.mesh_diameters - sc['diameter']).abs().max()) < 1e-7
+  for k, allow in (('rgbAs', 2e-4), ('xyz_mapAs', 2e-4), ('rgbBs', 1e-4), ('xyz_mapBs', 5e-4)):
+    frac, mx, _ = util.mismatch_report(ref[k].numpy(), getattr(pd, k).cpu().numpy(), 1.5e-3)
+    assert frac <= allow, f'{k}: {frac:.2e} (max {mx:.3f})'
+  if which == 'score':
+    frac, mx, _ = util.mismatch_report(ref['depthAs'].numpy(), pd.depthAs.cpu().numpy(), 2e-6)
+    assert frac <= 2e-4, f'depthAs: {frac:.2e} (max {mx:.2e})'
+    assert float((pd.depthBs.cpu() != ref['depthBs']).float().mean()) <= 5e-4
+    scorer = ScorePredictor(state_dict=S.make_score_state_dict(1), cfg=SCORE_DEFAULT)
+    f_step = scorer.forward_features(pd)
+    f_fused = scorer.extract_features(sc['rgb'], depth, sc['K'], poses, mesh_tensors=mt, mesh_diameter=sc['diameter'])
+    assert torch.equal(f_step, f_fused)
+    sub = pd.select_by_indices(torch.tensor([5, 2]))
+    assert torch.equal(scorer.forward_features(sub), f_step[[5, 2]])
+  else:
+    refiner = PoseRefinePredictor(state_dict=S.make_refine_state_dict(0), cfg=REFINE_DEFAULT)
+    cur = torch.from_numpy(poses).cuda()
+    for _ in range(2):
+      pd = make_crop_data_batch((160, 160), cur, None, sc['rgb'], depth, sc['K'], refiner.cfg['crop_ratio'], xyz_map,
+                                mesh_diameter=sc['diameter'], cfg=refiner.cfg, mesh_tensors=mt)
+      out = refiner.forward(pd)
+      cur = refiner.update_poses(pd.poseA, out['trans'], out['rot'], sc['diameter'])
+    fused, _ = refiner.predict(sc['rgb'], depth, sc['K'], poses, xyz_map, mesh_tensors=mt, mesh_diameter=sc['diameter'], iteration=2)
+    assert torch.equal(cur, fused)
+    assert torch.equal(out['trans'], refiner.last_trans_update) and torch.equal(out['rot'], refiner.last_rot_update)
+
+
 def test_depth_filters(sc, fp):
   from oracle import geometry as G
   U = fp['U']

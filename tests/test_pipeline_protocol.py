@@ -54,3 +54,26 @@ def test_obj_roundtrip_and_intrinsics(tmp_path):
   (tmp_path / 'bad.obj').write_text('# nothing\n')
   with pytest.raises(ValueError):
     load_obj(str(tmp_path / 'bad.obj'))
+
+
+def test_batch_pose_data_matches_reference(golden):
+  """BatchPoseData.select_by_indices against the reference's own class (tests/golden/gen_golden.py:168-171), plus the
+  record's own rules: unknown fields refused, the fused net tensor keeps side A over side B."""
+  import torch
+  from foundationpose_amd.pose_dataset import BatchPoseData, planar_views
+  bp = BatchPoseData(rgbAs=torch.arange(24.).reshape(4, 6), poseA=torch.arange(8.).reshape(4, 2))
+  sel = bp.select_by_indices(torch.tensor([2, 0]))
+  np.testing.assert_array_equal(sel.rgbAs.numpy(), golden['bpd_rgbAs'])
+  np.testing.assert_array_equal(sel.poseA.numpy(), golden['bpd_poseA'])
+  assert sel.rgbBs is None and sel.Ks is None and len(sel) == 2 and len(bp) == 4
+  assert bp.pin_memory() is bp
+  with pytest.raises(TypeError):
+    BatchPoseData(rgbs=torch.zeros(1))
+  net = torch.arange(6 * 2 * 2 * 8, dtype=torch.float16).reshape(6, 2, 2, 8)      # 3 hypotheses
+  bp = BatchPoseData(poseA=torch.arange(3.).reshape(3, 1), net_input=net)
+  sel = bp.select_by_indices([2, 1])
+  assert len(sel) == 2
+  np.testing.assert_array_equal(sel.net_input.numpy(), net[[2, 1, 5, 4]].numpy())
+  rgbA, xyzA, rgbB, xyzB = planar_views(net)
+  assert rgbA.shape == (3, 3, 2, 2) and rgbA.dtype == torch.float32
+  np.testing.assert_array_equal(xyzB[1, 2].numpy(), net[4, :, :, 5].float().numpy())
