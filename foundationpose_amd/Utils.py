@@ -235,6 +235,11 @@ def transform_dirs(dirs, tf):
   return (tf[..., :3, :3] @ dirs[..., None])[..., 0]
 
 
+def pose_to_egocentric_delta_pose(A_in_cam, B_in_cam):
+  """src/Utils.py:838-844: the inverse of egocentric_delta_pose_to_pose -> (trans_delta (B,3), rot_mat_delta (B,3,3))."""
+  return B_in_cam[:, :3, 3] - A_in_cam[:, :3, 3], B_in_cam[:, :3, :3] @ A_in_cam[:, :3, :3].transpose(1, 2)
+
+
 def egocentric_delta_pose_to_pose(A_in_cam, trans_delta, rot_mat_delta):
   """src/Utils.py:848-855"""
   B_in_cam = torch.eye(4, dtype=torch.float, device=A_in_cam.device)[None].expand(len(A_in_cam), -1, -1).contiguous()
