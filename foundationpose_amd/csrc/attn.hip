@@ -37,7 +37,7 @@ __global__ void vt_pad_zero_kernel(f16 *__restrict__ vt, int rows, int T) {
     *reinterpret_cast<uint4 *>(row + 408) = make_uint4(0, 0, 0, 0);
     return;
   }
-  for (int t = T; t < AT_TP; ++t) row[t] = (f16)0.f;
+  for (int t = T; t < AT_TP; ++t) row[vt_col(t)] = (f16)0.f;
 }
 
 int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s) {
@@ -58,8 +58,31 @@ int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s) {
 //                       the lane that owns query column q sees 16 of each 32 keys, its partner lane+32 the rest.
 //   online softmax     : per key block, max / sum finish with one xor-32 shuffle; exp((s-m)/sqrt(128)).
 //   O^T += V^T P^T     : the S^T accumulator registers 8s..8s+7 ARE the B operand of k-step s (key order
-//                       16s + {4h+0..3, 8+4h+0..3}); V^T comes from the transposed image as two 8-byte reads
-//                       in that same key order.  O^T keeps the query on the lane, so the rescale is lane-local.
+//                       16s + {4h+0..3, 8+4h+0..3}); the transposed V image stores its tokens in that order
+//                       (vt_col(), common.h), so a V^T fragment is ONE conflict-free ds_read_b128 like a K fragment.
+//                       O^T keeps the query on the lane, so the rescale is lane-local.
+// The loop is bound by vector-instruction ISSUE, not by the matrix pipe (SQ counters: 643 vector instructions per wave per
+// key block beside 32 MFMAs, two waves sharing one SIMD's issue port), so the body is written to issue few of them:
+// exp2 with the scale folded into one packed fma per two scores, v_max3, packed adds, tail masking only in the last key
+// block, O^T rescaled only when some lane's running max moved, LDS fragment offsets and DMA gather offsets precomputed
+// per lane (the DMA of a slot is scalar base + min(key, limit) * stride + lane constant - no branches in the loop).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool V> struct FaBool { static constexpr bool value = V; };
+
+// fmaxf() canonicalises each MFMA output first (one extra v_max per score); v_max3 from asm does not.  The hazard
+// recognizer does not look inside asm: an asm instruction must never be the FIRST reader of an MFMA result (the required
+// wait states would be missing and it would read a half-written accumulator) - the callers chain every fa_max3 behind a
+// compiler-visible instruction that reads the same accumulators (operand `a`).
+__device__ __forceinline__ float fa_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ void at_glds16s(const f16 *sbase, unsigned voff_bytes, f16 *l) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)l);
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(sbase), "s"(la) : "memory");
+}
+
 __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__restrict__ qk, const f16 *__restrict__ vt, int T,
                                                                   f16 *__restrict__ out, const f16 *__restrict__ zero_page) {
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
@@ -69,6 +92,7 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const size_t rowbase = (size_t)b * T;
+  const f16 *kbase = qk + rowbase * 1024 + 512 + h * AT_DH;              // K row `key` starts at kbase + key*1024
   const f16 *vsrc = vt + ((size_t)b * 4 + h) * AT_DH * AT_TP;
   const int nkb = (T + FA_KB - 1) / FA_KB;
 
@@ -91,21 +115,36 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
   half8 qf[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<half8 *>(&qv[s]);
-  auto stage = [&](int kb, int buf) {
-    f16 *kd = smem + buf * FA_STAGE_HALFS, *vd = kd + FA_KB * AT_DH;
+
+  // ---- DMA slots: instruction i = wave + 7u (mod 32) of a stage; i < 16 -> 64 lanes of the K block (64 keys x 16 chunks),
+  // else of the V^T block (128 dims x 8 chunks of 8 keys).  Byte offset from the scalar base of a slot for key block kb:
+  //   min(kb*64 + sx, limit) * stride + sadd     K: sx = key in block, limit T-1 (rows past T repeat the last one: their
+  //   scores are masked in the tail block), stride 2048;  V^T: sx = first key of the chunk, limit 408 (the last chunk of
+  //   the zero pad - P is exactly 0 past T, the operand must only be finite), stride 2.
+  unsigned sx[FA_DMA_PER_WAVE], sadd[FA_DMA_PER_WAVE];
+#pragma unroll
+  for (int u = 0; u < FA_DMA_PER_WAVE; ++u) {
+    int i = wave + u * FA_WAVES;
+    if (i >= 32) i -= 32;                                    // surplus slot: repeat an earlier instruction (same bytes)
+    if (i < 16) {
+      const int c = i * 64 + lane, kl = c >> 4, chp = c & 15;
+      sx[u] = kl;
+      sadd[u] = ((chp ^ (kl & 15)) * 8) * 2;
+    } else {
+      const int c = (i - 16) * 64 + lane, d = c >> 3, chp = c & 7;
+      sx[u] = (chp ^ ((d >> 1) & 7)) * 8;
+      sadd[u] = d * AT_TP * 2;
+    }
+  }
+  auto stage = [&](int kb, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < FA_DMA_PER_WAVE; ++u) {              // exactly FA_DMA_PER_WAVE per wave (vmcnt accounting)
       int i = wave + u * FA_WAVES;
-      if (i >= 32) i -= 32;                                  // surplus slot: repeat an earlier instruction (same bytes)
-      if (i < 16) {                                          // K block: 64 keys x 16 chunks
-        const int c = i * 64 + lane, kl = c >> 4, chp = c & 15, key = kb * FA_KB + kl;
-        const f16 *src = key < T ? qk + (rowbase + key) * 1024 + 512 + h * AT_DH + ((chp ^ (kl & 15)) * 8) : zero_page;
-        at_glds16(src, kd + i * 512);
-      } else {                                               // V^T block: 128 dims x 8 chunks of 8 keys
-        const int c = (i - 16) * 64 + lane, d = c >> 3, chp = c & 7, k0 = kb * FA_KB + ((chp ^ ((d >> 1) & 7)) * 8);
-        const f16 *src = k0 < AT_TP ? vsrc + (size_t)d * AT_TP + k0 : zero_page;
-        at_glds16(src, vd + (i - 16) * 512);
-      }
+      if (i >= 32) i -= 32;
+      const bool is_k = i < 16;                              // wave-uniform
+      const unsigned t = min((unsigned)(kb * FA_KB) + sx[u], is_k ? (unsigned)(T - 1) : 408u);
+      const unsigned voff = t * (is_k ? 2048u : 2u) + sadd[u];
+      at_glds16s(is_k ? kbase : vsrc, voff, smem + buf * FA_STAGE_HALFS + i * 512);
     }
   };
 #pragma unroll
@@ -113,15 +152,26 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
     if (p < nkb) stage(p, p);
   __builtin_amdgcn_sched_barrier(0);
 
+  // ---- LDS fragment offsets (bytes, within a stage) ----
+  //   K: row (kt*32 + lr), chunk (2*s + lh) ^ (lr & 15), s = 0..7; kt adds 8192 B
+  //   V^T: row (dt*32 + lr), chunk (2*s + lh) ^ ((lr>>1)&7), s = 0..3 (k-steps of 16 keys); dt adds 4096 B
+  unsigned koffb[8], voffb[4];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) koffb[s] = (lr * AT_DH + (((2 * s + lh) ^ (lr & 15)) * 8)) * 2;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) voffb[s] = FA_KB * AT_DH * 2 + (lr * FA_KB + (((2 * s + lh) ^ ((lr >> 1) & 7)) * 8)) * 2;
+
   floatx16 oacc[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
-  const float scale = 0.08838834764831845f;  // 1/sqrt(128)
+  const float c2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128): exp((s-m)/sqrt(128)) = exp2(s*c2 - m*c2)
+  const f32x2 c2v = {c2, c2};
 
-  for (int kb = 0; kb < nkb; ++kb) {
+  auto body = [&](const int kb, auto tail_c) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail_c)::value;           // this block holds keys >= T
     // block kb must have landed; the (up to two) younger blocks stay in flight across the barrier
     const int younger = min(nkb - 1 - kb, FA_NSTAGE - 2);
     if (younger >= 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
@@ -130,12 +180,8 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (kb + FA_NSTAGE - 1 < nkb) stage(kb + FA_NSTAGE - 1, (kb + FA_NSTAGE - 1) % FA_NSTAGE);   // ring slot of block kb-1: free
-    const f16 *kd = smem + (kb % FA_NSTAGE) * FA_STAGE_HALFS, *vd = kd + FA_KB * AT_DH;
+    const char *sb = reinterpret_cast<const char *>(smem) + (kb % FA_NSTAGE) * (FA_STAGE_HALFS * 2);
     floatx16 sacc[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
     // two independent accumulation chains (key tiles 0/1), fragments fetched four k-steps at a time so that
     // eight LDS reads are in flight before the first MFMA of the group issues
 #pragma unroll
@@ -144,72 +190,85 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-          kf[kt][s] = *reinterpret_cast<const half8 *>(&kd[(kt * 32 + lr) * AT_DH + (((2 * (sh * 4 + s) + lh) ^ (lr & 15)) * 8)]);
+        for (int kt = 0; kt < 2; ++kt) kf[kt][s] = *reinterpret_cast<const half8 *>(sb + koffb[sh * 4 + s] + kt * (32 * AT_DH * 2));
+      __builtin_amdgcn_sched_barrier(0);                     // all eight reads issue before the first MFMA waits for one
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[sh * 4 + s], sacc[kt], 0, 0, 0);
+        for (int kt = 0; kt < 2; ++kt) {
+          if (sh == 0 && s == 0) {
+            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[0], zero, 0, 0, 0);
+          } else {
+            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[sh * 4 + s], sacc[kt], 0, 0, 0);
+          }
+        }
     }
-    // ---- online softmax for query column lr (only the last key block can hold keys >= T) ----
-    const bool tail = (kb + 1) * FA_KB > T;
-    float bm = -1.0e30f;
+    // ---- online softmax for query column lr ----
+    if constexpr (TAIL) {                                   // keys >= T: score -1e30 -> out of the max, exp2 -> exactly 0
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb * FA_KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (!tail || key < T) bm = fmaxf(bm, sacc[kt][r]);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * FA_KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          sacc[kt][r] = key < T ? sacc[kt][r] : -1.0e30f;
+        }
+    }
+    float bm = fmaxf(sacc[0][15], sacc[1][15]);              // compiler-visible first reader of both accumulators
+    bm = fa_max3(bm, sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 15; r += 2) bm = fa_max3(bm, sacc[0][r], sacc[0][r + 1]);
+#pragma unroll
+    for (int r = 1; r < 15; r += 2) bm = fa_max3(bm, sacc[1][r], sacc[1][r + 1]);
     bm = fmaxf(bm, __shfl_xor(bm, 32));
     const float m_new = fmaxf(m_run, bm);
-    const float alpha = __expf((m_run - m_new) * scale);
-    float ps = 0.f;
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+    const float nmc = -m_new * c2;
+    const f32x2 nmcv = {nmc, nmc};
+    f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kb * FA_KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float e = (!tail || key < T) ? __expf((sacc[kt][r] - m_new) * scale) : 0.f;
-        sacc[kt][r] = e;
-        ps += e;
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sv = {sacc[kt][r], sacc[kt][r + 1]};
+        const f32x2 ev = __builtin_elementwise_fma(sv, c2v, nmcv);
+        const f32x2 e = {__builtin_amdgcn_exp2f(ev.x), __builtin_amdgcn_exp2f(ev.y)};
+        sacc[kt][r] = e.x;
+        sacc[kt][r + 1] = e.y;
+        ps2 += e;
       }
+    float ps = ps2.x + ps2.y;
     ps += __shfl_xor(ps, 32);
     l_run = l_run * alpha + ps;
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {    // some lane's maximum moved: rescale O^T (alpha == 1 elsewhere)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+    }
     m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
     // ---- O^T += V^T P^T ----
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kt = 0; kt < 2; ++kt) {
+      half8 pf[2], vf[2][4];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        half8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (f16)sacc[kt][8 * s2 + j];
-        const int chunk = kt * 4 + 2 * s2;
-        half4 v0[4], v1[4];
+        for (int j = 0; j < 8; ++j) pf[s2][j] = (f16)sacc[kt][8 * s2 + j];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const int d = dt * 32 + lr, sw = (d >> 1) & 7;
-          const f16 *vrow = vd + d * FA_KB + 4 * lh;
-          v0[dt] = *reinterpret_cast<const half4 *>(vrow + ((chunk ^ sw) * 8));
-          v1[dt] = *reinterpret_cast<const half4 *>(vrow + (((chunk + 1) ^ sw) * 8));
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          half8 vf;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            vf[j] = v0[dt][j];
-            vf[4 + j] = v1[dt][j];
-          }
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[dt], 0, 0, 0);
-        }
+        for (int dt = 0; dt < 4; ++dt) vf[s2][dt] = *reinterpret_cast<const half8 *>(sb + voffb[kt * 2 + s2] + dt * (32 * FA_KB * 2));
       }
-  }
+      __builtin_amdgcn_sched_barrier(0);                     // eight V^T reads in flight before the first MFMA waits
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][dt], pf[s2], oacc[dt], 0, 0, 0);
+    }
+  };
+  for (int kb = 0; kb < nkb - 1; ++kb) body(kb, FaBool<false>{});
+  if (nkb * FA_KB > T) body(nkb - 1, FaBool<true>{});
+  else body(nkb - 1, FaBool<false>{});
+
   // O^T accumulator: col = query lr, row = dim (r&3) + 8*(r>>2) + 4*lh of each 32-dim tile -> 8-byte stores
   if (q < T) {
     const float inv = 1.f / l_run;

@@ -185,11 +185,15 @@ struct ConvArgs {
   const float *post_add;
   void *out;
   int Nimg, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, Kpad, M;
-  int relu, out_mode;  // 0 fp16 NHWC, 1 fp32 NHWC, 2 fp16 V-transposed [b][4][128][416]
+  int relu, out_mode;  // 0 fp16 NHWC, 1 fp32 NHWC, 2 fp16 V-transposed [b][4][128][416], token t in column vt_col(t)
   int out_ld, split_m, coff_hi, post_period, tokens;
 };
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
+// Column of token t inside the transposed V image [b][4][128][416].  Within each group of 16 tokens the order is
+// {0-3, 8-11, 4-7, 12-15}: the 8 keys that one lane half of the attention kernel's P^T operand carries (the S^T
+// accumulator registers of a k-step) are then 16 contiguous bytes - one ds_read_b128 per V^T fragment.
+__host__ __device__ __forceinline__ int vt_col(int t) { return (t & ~15) | (((t >> 2) & 1) << 3) | (((t >> 3) & 1) << 2) | (t & 3); }
 int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s);
 int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s);
 int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);

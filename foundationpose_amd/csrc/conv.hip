@@ -323,7 +323,7 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
     int tb = 0, tt = 0;
     if (p.out_mode == 2) {
       tb = m / p.tokens;
-      tt = m - tb * p.tokens;
+      tt = vt_col(m - tb * p.tokens);
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {

@@ -170,7 +170,9 @@ int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const fp_mesh *mes
 int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin, const void *d_w_packed, const float *d_bias,
                   int Cout, int KH, int KW, int stride, int pad, const void *d_res, int relu, void *d_out, int out_f32,
                   void *stream);
-/* fused multi-head self-attention core, 4 heads x 128: qk [M][1024] fp16 (q|k), vt [B][4][128][416] fp16 -> out [M][512] fp16 */
+/* fused multi-head self-attention core, 4 heads x 128: qk [M][1024] fp16 (q|k), vt [B][4][128][416] fp16 -> out [M][512] fp16.
+ * vt is V transposed, token t of a hypothesis in column (t & ~15) | ((t>>2 & 1) << 3) | ((t>>3 & 1) << 2) | (t & 3)
+ * (tokens of a group of 16 in the order 0-3, 8-11, 4-7, 12-15); columns of tokens >= T must hold zeros. */
 int fp_attention_f16(fp_ctx *ctx, const void *d_qk, const void *d_vt, int B, int T, void *d_out, void *stream);
 
 /* mycpp.cluster_poses (mycpp/src/app/pybind_api.cpp:24-68); host function, float32 row-major 4x4.

@@ -322,16 +322,21 @@ def test_conv_rejects_bad_shapes(fp):
     check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(x), 1, 4, 4, 48, ptr(w), ptr(b), 64, 3, 3, 1, 1, None, 1, ptr(o), 0, stream_ptr()))
 
 
-def test_attention_vs_reference(fp):
+@pytest.mark.parametrize('T', [400, 384, 230, 64, 37, 1])
+def test_attention_vs_reference(fp, T):
   """Fused MHA core vs softmax(QK^T/sqrt(128))V in fp32 on the same fp16 operands.  P is rounded to
-  fp16 before the PV MFMA: |err| <= 2^-11 * sum|p v| -> atol 2e-3 on O(1) values."""
+  fp16 before the PV MFMA: |err| <= 2^-11 * sum|p v| -> atol 2e-3 on O(1) values.  T = 400 is the networks' token
+  count (tail key block 16/64 full); 384 and 64 end on a block boundary (no tail), 230 needs two query blocks with a
+  partly empty second one, 37 and 1 are single partial blocks."""
   from foundationpose_amd._lib import check, lib, ptr, stream_ptr
   g = torch.Generator().manual_seed(5)
-  B, T = 3, 400
+  B = 3
   qk = (torch.randn((B * T, 1024), generator=g) * 1.5).half()
   v = torch.randn((B * T, 512), generator=g).half()
   vt = torch.zeros((B, 4, 128, 416), dtype=torch.float16)
-  vt[..., :T] = v.reshape(B, T, 4, 128).permute(0, 2, 3, 1)
+  t = np.arange(T)
+  col = (t & ~15) | (((t >> 2) & 1) << 3) | (((t >> 3) & 1) << 2) | (t & 3)       # the image's token order (foundationpose_amd.h)
+  vt[..., torch.from_numpy(col)] = v.reshape(B, T, 4, 128).permute(0, 2, 3, 1)
   out = torch.empty((B * T, 512), dtype=torch.float16, device='cuda')
   qk_d, vt_d = qk.cuda(), vt.cuda()
   check(lib().fp_attention_f16(fp['ctx'].handle, ptr(qk_d), ptr(vt_d), B, T, ptr(out), stream_ptr()))
