@@ -306,7 +306,17 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
         }
       }
     }
-    ISTAMP(if (lane == 0 && blockIdx.x < 4096) { unsigned long long *o = g_igemm_stamps + ((size_t)blockIdx.x * 4 + wave) * 4; o[0] = t_loop - t_entry; o[1] = t_epi - t_loop; o[2] = __builtin_amdgcn_s_memtime() - t_epi; o[3] = 1; })
+    ISTAMP(if (lane == 0 && blockIdx.x < 4096) {
+      unsigned long long *o = g_igemm_stamps + ((size_t)blockIdx.x * 4 + wave) * 4;
+      const unsigned long long t_exit = __builtin_amdgcn_s_memtime();
+      if (wave == 1) {          // wave 1: absolute entry / exit times and the hardware slot (HW_ID | XCC_ID << 32): per-CU timelines
+        o[0] = t_entry; o[1] = t_exit;
+        o[2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+      } else {
+        o[0] = t_loop - t_entry; o[1] = t_epi - t_loop; o[2] = t_exit - t_epi;
+      }
+      o[3] = 1;
+    })
     return;
   }
 

@@ -25,7 +25,30 @@ for name, (M, K, N, use_res) in {'linear 512->512 +res': (100800, 512, 512, True
   e1.record(); torch.cuda.synchronize()
   buf = np.zeros((4096, 4, 4), dtype=np.uint64)
   L.fp_dbg_igemm_stamps(buf.ctypes.data_as(ctypes.c_void_p))
-  v = buf[:400].reshape(-1, 4).astype(np.float64)
+  v = buf[:400, [0, 2, 3]].reshape(-1, 4).astype(np.float64)
   v = v[v[:, 3] > 0]
   m = v.mean(0)
   print(f'{name:22s} {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us   prologue {m[0]:7.0f}  K loop {m[1]:7.0f}  epilogue {m[2]:7.0f} cycles')
+  # per-CU timelines from wave 1 of every workgroup: how many workgroups share a CU at a time, gaps between them
+  w1 = buf[:, 1]
+  w1 = w1[w1[:, 3] > 0]
+  t0, t1, hw = w1[:, 0].astype(np.int64), w1[:, 1].astype(np.int64), w1[:, 2]
+  cu = ((hw >> 32) & 0xf) * 4096 + (hw & 0xffffffff & 0xff00) // 256 * 1 + (((hw >> 13) & 7) * 64) + (((hw >> 12) & 1) * 32)   # xcc, cu_id, se_id, sh_id
+  span = t1.max() - t0.min()
+  life = (t1 - t0)
+  print(f'   {len(w1)} workgroups on {len(np.unique(cu))} CUs; kernel span {span} ticks; workgroup life mean {life.mean():.0f} (min {life.min()}, max {life.max()})')
+  conc, gaps = [], []
+  for c in np.unique(cu)[:64]:
+    sel = cu == c
+    ev = sorted([(a, 1) for a in t0[sel]] + [(b, -1) for b in t1[sel]])
+    cur, last, busy2, busy1, idle = 0, ev[0][0], 0, 0, 0
+    for t, d in ev:
+      dt = t - last
+      if cur >= 2: busy2 += dt
+      elif cur == 1: busy1 += dt
+      else: idle += dt
+      cur += d; last = t
+    conc.append((busy2, busy1, idle, sel.sum()))
+  conc = np.array(conc, dtype=np.float64)
+  tot = conc[:, :3].sum(1)
+  print(f'   per CU (first 64): {conc[:, 3].mean():.1f} workgroups; time with >=2 resident {100 * (conc[:, 0] / tot).mean():.0f} %, 1 resident {100 * (conc[:, 1] / tot).mean():.0f} %, none {100 * (conc[:, 2] / tot).mean():.0f} %')

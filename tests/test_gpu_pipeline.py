@@ -275,3 +275,41 @@ def test_other_frame_size_and_intrinsics(estimators):
   # the integrated call on this frame (device prelude: filtering, stats, float64 back-projection)
   pose = est.register(K=K, rgb=sc['rgb'], depth=sc['depth'], ob_mask=sc['mask'], iteration=1)
   assert pose.shape == (4, 4) and np.isfinite(pose).all()
+
+
+@pytest.mark.parametrize('variant', ['plain_xyz_tanh', '6d_no_bn'])
+def test_predictors_other_config_branches(variant):
+  """The config branches the released models do not take but the reference implements (predict_pose_refine.py:195-231,
+  h5_dataset.py:92-99,151-156): normalize_xyz=False (xyz only centred, translation through tanh * trans_normalizer) and
+  rot_rep='6d' without BatchNorm.  8 hypotheses, 2 iterations, through PoseRefinePredictor / ScorePredictor vs the oracle's
+  predict loops: poses within 1e-3 (north_star), same best hypothesis, logits within 2e-3."""
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.config import REFINE_DEFAULT, SCORE_DEFAULT
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+  from foundationpose_amd.predict_score import ScorePredictor
+  from oracle import geometry as G, predict as OP
+  sc = util.scene(0)
+  poses = util.hypotheses(sc, 8, jitter_seed=11)
+  depth = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+  xyz_map = G.depth2xyzmap(depth, sc['K'])
+  mt = util.to_dev(sc['mt'])
+  if variant == 'plain_xyz_tanh':
+    rcfg = dict(REFINE_DEFAULT, normalize_xyz=False)
+    scfg = dict(SCORE_DEFAULT, normalize_xyz=False)
+    rsd, ssd = S.make_refine_state_dict(0), S.make_score_state_dict(1)
+  else:
+    rcfg = dict(REFINE_DEFAULT, rot_rep='6d', use_BN=False)
+    scfg = dict(SCORE_DEFAULT, use_BN=False)
+    rsd, ssd = S.make_refine_state_dict(seed=2, use_bn=False, rot_out_dim=6), S.make_score_state_dict(seed=3, use_bn=False)
+  refiner = PoseRefinePredictor(state_dict=rsd, cfg=rcfg)
+  got, _ = refiner.predict(sc['rgb'], depth, sc['K'], poses, xyz_map, mesh_tensors=mt, mesh_diameter=sc['diameter'], iteration=2)
+  ocfg = dict(OP.DEFAULT_REFINE_CFG, **{k: rcfg[k] for k in ('normalize_xyz', 'rot_rep', 'use_BN')})
+  ref = OP.refine_predict(ocfg, rsd, sc['rgb'], depth, sc['K'], poses, xyz_map, sc['mt'], sc['diameter'], iteration=2, chunk=8)
+  assert float((torch.as_tensor(poses) - ref).abs().max()) > 1e-3          # the networks moved the poses
+  np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=1e-3)
+  scorer = ScorePredictor(state_dict=ssd, cfg=scfg)
+  s_got, _ = scorer.predict(sc['rgb'], depth, sc['K'], ref.numpy(), mesh_tensors=mt, mesh_diameter=sc['diameter'])
+  oscfg = dict(OP.DEFAULT_SCORE_CFG, **{k: scfg[k] for k in ('normalize_xyz', 'use_BN')})
+  s_ref = OP.score_predict(oscfg, ssd, sc['rgb'], depth, sc['K'], ref.numpy(), sc['mt'], sc['diameter'], chunk=8)
+  np.testing.assert_allclose(s_got.cpu().numpy(), s_ref.numpy(), atol=2e-3)
+  assert int(s_got.argmax()) == int(s_ref.argmax())
