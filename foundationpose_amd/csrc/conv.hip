@@ -16,6 +16,7 @@
 // have their own kernel (conv_halo.hip).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define CV_BK 32
 
@@ -210,19 +211,20 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
     }
   }
 
-  // ---- epilogue, fp16 NHWC: residual staged through LDS, fp32 math, LDS transpose, 16-byte row stores.  RES is a
-  // compile-time flag, ReLU a branch-free max against 0 or -inf, the residual tile is requested in ONE batch before the
-  // barrier (the main loop's fragment registers are dead) - the K loop of a Linear layer is only 16 steps long, so this
-  // epilogue weighs as much as the loop itself ----
+  // ---- epilogue, fp16 NHWC: residual staged through LDS and added in fp32, LDS transpose, 16-byte row stores.  The K loop
+  // of a Linear layer is only 16 steps long, so the epilogue weighs a quarter of the tile; it is written to issue few vector
+  // instructions: ReLU on the packed fp16 pair after conversion (rounding is monotonic and keeps 0: same result as before
+  // it), no per-row output select when the whole tile lies on one side of split_m.  (Reading the residual as 8-byte
+  // gathers in the accumulator layout behind the first DMA stages was measured: epilogue -6.8k cycles, K loop +16k.) ----
   ISTAMP(const unsigned long long t_epi = __builtin_amdgcn_s_memtime();)
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   if (p.out_mode == 0) {
     f16 *stage = smem;
     constexpr int CPR = BM / 8;           // 16-byte chunks per staged row
     constexpr int NCH = TN * CPR / 256;
     constexpr int RB = NCH < 8 ? NCH : 8;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 rv[NCH];
-    if constexpr (RES) {
+    if constexpr (RES) {                  // residual tile: ONE batch of coalesced 16-byte loads before the barrier, staged through LDS
 #pragma unroll
       for (int u = 0; u < NCH; ++u) {
         const int idx = tid + 256 * u, px = idx / CPR, c16 = idx % CPR;
@@ -230,7 +232,6 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
         rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
       }
     }
-    const float lo = p.relu ? 0.f : -__builtin_inff();
     __syncthreads();
     if constexpr (RES) {
 #pragma unroll
@@ -239,70 +240,96 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
         *reinterpret_cast<u32x4 *>(&stage[px * SLD + c16 * 8]) = rv[u];
       }
       __syncthreads();
-    }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int pxl = wn * (32 * NT) + j * 32 + lr;
-      float4 pvs[MT][4];
-      if (p.post_add) {
+      for (int j = 0; j < NT; ++j) {      // each lane reads back exactly the 8-byte slots it overwrites below: no barrier in between
+        const int pxl = wn * (32 * NT) + j * 32 + lr;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const half4 rq = *reinterpret_cast<const half4 *>(&stage[pxl * SLD + wm * WM + i * 32 + rg * 8 + lh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][rg * 4 + e] += (float)rq[e];
+          }
+      }
+    }
+    if (p.post_add) {                     // fp32 add after the ReLU (positional embedding): one layer per forward
+      const float lo = p.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int pxl = wn * (32 * NT) + j * 32 + lr;
         const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg)
-            pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
-      }
-      half4 rq[MT][4];
-      if constexpr (RES) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) rq[i][rg] = *reinterpret_cast<const half4 *>(&stage[pxl * SLD + wm * WM + i * 32 + rg * 8 + lh * 4]);
-      }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int col = wm * WM + i * 32 + rg * 8 + lh * 4;
-          float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
-          if constexpr (RES) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][rg][e];
+          for (int rg = 0; rg < 4; ++rg) {
+            const int col = wm * WM + i * 32 + rg * 8 + lh * 4;
+            const float4 pv = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + col);
+            half4 hv;
+            hv[0] = (f16)(fmaxf(acc[i][j][rg * 4 + 0], lo) + pv.x);
+            hv[1] = (f16)(fmaxf(acc[i][j][rg * 4 + 1], lo) + pv.y);
+            hv[2] = (f16)(fmaxf(acc[i][j][rg * 4 + 2], lo) + pv.z);
+            hv[3] = (f16)(fmaxf(acc[i][j][rg * 4 + 3], lo) + pv.w);
+            *reinterpret_cast<half4 *>(&stage[pxl * SLD + col]) = hv;
           }
+      }
+    } else {
+      auto convert = [&](auto relu_c) __attribute__((always_inline)) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
-          if (p.post_add) {
-            const float4 pv = pvs[i][rg];
-            v[0] += pv.x;
-            v[1] += pv.y;
-            v[2] += pv.z;
-            v[3] += pv.w;
-          }
-          half4 hv;
+        for (int j = 0; j < NT; ++j) {
+          const int pxl = wn * (32 * NT) + j * 32 + lr;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
-          *reinterpret_cast<half4 *>(&stage[pxl * SLD + col]) = hv;
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              half4 hv;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) hv[e] = (f16)acc[i][j][rg * 4 + e];
+              if constexpr (decltype(relu_c)::value) hv = __builtin_elementwise_max(hv, half4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f});
+              *reinterpret_cast<half4 *>(&stage[pxl * SLD + wm * WM + i * 32 + rg * 8 + lh * 4]) = hv;
+            }
         }
-      }
+      };
+      if (p.relu) convert(std::true_type{});
+      else convert(std::false_type{});
     }
     __syncthreads();
+    const bool side_hi = m0 >= p.split_m;
+    if (side_hi || m0 + TN <= p.split_m) {          // whole tile on one side: one scalar base, rows at a fixed stride
+      f16 *obase = (f16 *)p.out + (long long)(side_hi ? m0 - p.split_m : m0) * p.out_ld + (side_hi ? p.coff_hi : 0) + c0;
 #pragma unroll
-    for (int i0 = 0; i0 < NCH; i0 += RB) {
-      uint4 ov[RB];
+      for (int i0 = 0; i0 < NCH; i0 += RB) {
+        uint4 ov[RB];
 #pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
-        ov[u] = *reinterpret_cast<const uint4 *>(&stage[px * SLD + c16 * 8]);
+        for (int u = 0; u < RB; ++u) {
+          const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
+          ov[u] = *reinterpret_cast<const uint4 *>(&stage[px * SLD + c16 * 8]);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
+          if (m0 + px < p.M) *reinterpret_cast<uint4 *>(obase + (long long)px * p.out_ld + c16 * 8) = ov[u];
+        }
       }
+    } else {
 #pragma unroll
-      for (int u = 0; u < RB; ++u) {
-        const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
-        const int m = m0 + px;
-        if (m < p.M) {
-          const bool hi = m >= p.split_m;
-          const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
-          const int coff = hi ? p.coff_hi : 0;
-          *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
+      for (int i0 = 0; i0 < NCH; i0 += RB) {
+        uint4 ov[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
+          ov[u] = *reinterpret_cast<const uint4 *>(&stage[px * SLD + c16 * 8]);
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const int idx = tid + 256 * (i0 + u), px = idx / CPR, c16 = idx % CPR;
+          const int m = m0 + px;
+          if (m < p.M) {
+            const bool hi = m >= p.split_m;
+            const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+            const int coff = hi ? p.coff_hi : 0;
+            *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
+          }
         }
       }
     }

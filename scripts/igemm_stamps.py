@@ -36,7 +36,10 @@ for name, (M, K, N, use_res) in {'linear 512->512 +res': (100800, 512, 512, True
   cu = ((hw >> 32) & 0xf) * 4096 + (hw & 0xffffffff & 0xff00) // 256 * 1 + (((hw >> 13) & 7) * 64) + (((hw >> 12) & 1) * 32)   # xcc, cu_id, se_id, sh_id
   span = t1.max() - t0.min()
   life = (t1 - t0)
-  print(f'   {len(w1)} workgroups on {len(np.unique(cu))} CUs; kernel span {span} ticks; workgroup life mean {life.mean():.0f} (min {life.min()}, max {life.max()})')
+  print(f'   {len(w1)} workgroups on {len(np.unique(cu))} CUs; workgroup life mean {life.mean():.0f} (min {life.min()}, max {life.max()})')
+  spans = np.array([t1[cu == c].max() - t0[cu == c].min() for c in np.unique(cu)], dtype=np.float64)
+  us = e0.elapsed_time(e1) / 20 * 1e3
+  print(f'   per-CU span (first entry -> last exit) median {np.median(spans):.0f} ticks over {us:.1f} us -> {np.median(spans) / us / 1e3:.2f} GHz if a tick is a shader cycle')
   conc, gaps = [], []
   for c in np.unique(cu)[:64]:
     sel = cu == c
