@@ -12,6 +12,10 @@
 #define AT_MAXT 400
 #define FA_WAVES 7
 #define FA_NSTAGE 4
+#define FA_AHEAD 2      // key blocks the DMA runs ahead: slot kb-1 must survive iteration kb for the staggered waves
+#ifndef FA_STAGGER
+#define FA_STAGGER 1
+#endif
 #define FA_DMA_PER_WAVE 5   // ceil(32 DMA instructions per stage / 7 waves); surplus slots repeat an earlier one
 #define FA_THREADS (FA_WAVES * 64)
 #define FA_QB (FA_WAVES * 32)   // queries per workgroup
@@ -69,6 +73,18 @@ int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool V> struct FaBool { static constexpr bool value = V; };
 
+#ifdef HALO_STAMP
+// diagnostic build only (make -B EXTRA=-DHALO_STAMP): per-wave s_memtime stamps of the attention kernel, first 1024 workgroups:
+// [0] entry, [1] Q landed, [2] prologue DMA issued, then per key block {barrier passed, S done, softmax done, PV done}, [31] exit
+__device__ unsigned long long g_attn_stamps[1024 * 7 * 32];
+extern "C" int fp_dbg_attn_stamps(unsigned long long *host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)) == hipSuccess ? 0 : -1;
+}
+#define ASTAMP(i) do { if (blockIdx.x < 1024) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+
 // fmaxf() canonicalises each MFMA output first (one extra v_max per score); v_max3 from asm does not.  The hazard
 // recognizer does not look inside asm: an asm instruction must never be the FIRST reader of an MFMA result (the required
 // wait states would be missing and it would read a half-written accumulator) - the callers chain every fa_max3 behind a
@@ -99,22 +115,13 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
   // Q^T fragments: loaded by inline asm and waited for by hand BEFORE the first LDS-DMA is issued.  With a
   // compiler-visible load, hipcc sinks it below the DMAs and then drains vmcnt(0) at the first use of qf inside
   // the key loop - every iteration - which serialises the whole DMA ring.
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifdef HALO_STAMP
+  unsigned long long st[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) st[i] = 0;
+#endif
+  ASTAMP(0);
   const int q = qb * FA_QB + wave * 32 + lr;
-  u32x4 qv[8];
-  {
-    const f16 *qsrc = q < T ? qk + (rowbase + q) * 1024 + h * AT_DH + lh * 8 : zero_page;
-    const int step = q < T ? 16 : 0;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qv[s]) : "v"(qsrc + s * step) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]), "+v"(qv[4]), "+v"(qv[5]), "+v"(qv[6]), "+v"(qv[7])
-                 :
-                 : "memory");
-  }
-  half8 qf[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<half8 *>(&qv[s]);
 
   // ---- DMA slots: instruction i = wave + 7u (mod 32) of a stage; i < 16 -> 64 lanes of the K block (64 keys x 16 chunks),
   // else of the V^T block (128 dims x 8 chunks of 8 keys).  Byte offset from the scalar base of a slot for key block kb:
@@ -147,10 +154,33 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
       at_glds16s(is_k ? kbase : vsrc, voff, smem + buf * FA_STAGE_HALFS + i * 512);
     }
   };
+  // Prologue: both key blocks' DMAs first, then Q^T - the Q latency hides under theirs (a workgroup is alone on its CU:
+  // nothing else covers its start-up; stamps: Q 7.5k + DMA issue 2.9k + block-0 wait 6.8k of a 47k-cycle life when Q was
+  // loaded and waited for first).  Q^T fragments are loaded by inline asm and waited for by hand, the wait directly behind
+  // the loads: with a compiler-visible load, hipcc sinks it below the DMAs and then drains vmcnt(0) at the first use of qf
+  // inside the key loop - every iteration - which serialises the whole DMA ring; with other code between the asm loads and
+  // the asm wait it may copy the destination registers before the data has landed.
 #pragma unroll
-  for (int p = 0; p < FA_NSTAGE - 1; ++p)
+  for (int p = 0; p < FA_AHEAD; ++p)
     if (p < nkb) stage(p, p);
+  ASTAMP(1);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 qv[8];
+  {
+    const f16 *qsrc = q < T ? qk + (rowbase + q) * 1024 + h * AT_DH + lh * 8 : zero_page;
+    const int step = q < T ? 16 : 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qv[s]) : "v"(qsrc + s * step) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]), "+v"(qv[4]), "+v"(qv[5]), "+v"(qv[6]), "+v"(qv[7])
+                 :
+                 : "memory");
+  }
+  half8 qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<half8 *>(&qv[s]);
   __builtin_amdgcn_sched_barrier(0);
+  ASTAMP(2);
 
   // ---- LDS fragment offsets (bytes, within a stage) ----
   //   K: row (kt*32 + lr), chunk (2*s + lh) ^ (lr & 15), s = 0..7; kt adds 8192 B
@@ -170,16 +200,40 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
   const float c2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128): exp((s-m)/sqrt(128)) = exp2(s*c2 - m*c2)
   const f32x2 c2v = {c2, c2};
 
-  auto body = [&](const int kb, auto tail_c) __attribute__((always_inline)) {
+  // One key block of one wave: S^T -> softmax -> P^T (packed fp16), and O^T += V^T P^T.  Waves 4-6 (the second wave on
+  // their SIMD) run the PV product of block kb-1 at the START of iteration kb and keep P^T across the barrier, so a SIMD
+  // pairs one wave's MFMAs with the other's softmax instead of running the same phase on both (FA_STAGGER).
+  half8 pfc[2][2];                                             // P^T of the block whose PV product is still owed (late waves)
+  auto pv_phase = [&](const int kb, const half8 (&pf)[2][2]) __attribute__((always_inline)) {
+    const char *sb = reinterpret_cast<const char *>(smem) + (kb % FA_NSTAGE) * (FA_STAGE_HALFS * 2);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      half8 vf[2][4];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vf[s2][dt] = *reinterpret_cast<const half8 *>(sb + voffb[kt * 2 + s2] + dt * (32 * FA_KB * 2));
+      __builtin_amdgcn_sched_barrier(0);                     // eight V^T reads in flight before the first MFMA waits
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][dt], pf[kt][s2], oacc[dt], 0, 0, 0);
+    }
+  };
+  auto body = [&](const int kb, auto tail_c, auto late_c) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_c)::value;           // this block holds keys >= T
-    // block kb must have landed; the (up to two) younger blocks stay in flight across the barrier
-    const int younger = min(nkb - 1 - kb, FA_NSTAGE - 2);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    constexpr bool LATE = decltype(late_c)::value;
+    // block kb must have landed; the next block stays in flight across the barrier
+    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (kb + FA_NSTAGE - 1 < nkb) stage(kb + FA_NSTAGE - 1, (kb + FA_NSTAGE - 1) % FA_NSTAGE);   // ring slot of block kb-1: free
+    ASTAMP(3 + 4 * kb);
+    // ring slot of block kb-2: every wave is past it (the late waves finished PV(kb-2) in iteration kb-1)
+    if (kb + FA_AHEAD < nkb) stage(kb + FA_AHEAD, (kb + FA_AHEAD) % FA_NSTAGE);
+    if constexpr (LATE) {
+      if (kb > 0) pv_phase(kb - 1, pfc);
+    }
     const char *sb = reinterpret_cast<const char *>(smem) + (kb % FA_NSTAGE) * (FA_STAGE_HALFS * 2);
     floatx16 sacc[2];
     // two independent accumulation chains (key tiles 0/1), fragments fetched four k-steps at a time so that
@@ -204,6 +258,8 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
           }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(4 + 4 * kb);
     // ---- online softmax for query column lr ----
     if constexpr (TAIL) {                                   // keys >= T: score -1e30 -> out of the max, exp2 -> exactly 0
 #pragma unroll
@@ -247,28 +303,44 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
         for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
     }
     m_run = m_new;
-    // ---- O^T += V^T P^T ----
+    // ---- P^T, and O^T += V^T P^T now (early waves) or at the start of the next iteration (late waves) ----
+    half8 pf[2][2];
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      half8 pf[2], vf[2][4];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[s2][j] = (f16)sacc[kt][8 * s2 + j];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vf[s2][dt] = *reinterpret_cast<const half8 *>(sb + voffb[kt * 2 + s2] + dt * (32 * FA_KB * 2));
-      }
-      __builtin_amdgcn_sched_barrier(0);                     // eight V^T reads in flight before the first MFMA waits
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][dt], pf[s2], oacc[dt], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) pf[kt][s2][j] = (f16)sacc[kt][8 * s2 + j];
+    __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(5 + 4 * kb);
+    if constexpr (LATE) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) pfc[kt][s2] = pf[kt][s2];
+    } else {
+      pv_phase(kb, pf);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    ASTAMP(6 + 4 * kb);
   };
-  for (int kb = 0; kb < nkb - 1; ++kb) body(kb, FaBool<false>{});
-  if (nkb * FA_KB > T) body(nkb - 1, FaBool<true>{});
-  else body(nkb - 1, FaBool<false>{});
+  auto run = [&](auto late_c) __attribute__((always_inline)) {
+    for (int kb = 0; kb < nkb - 1; ++kb) body(kb, FaBool<false>{}, late_c);
+    if (nkb * FA_KB > T) body(nkb - 1, FaBool<true>{}, late_c);
+    else body(nkb - 1, FaBool<false>{}, late_c);
+    if constexpr (decltype(late_c)::value) pv_phase(nkb - 1, pfc);
+  };
+  if (FA_STAGGER && wave >= 4) run(FaBool<true>{});
+  else run(FaBool<false>{});
 
+#ifdef HALO_STAMP
+  if (blockIdx.x < 1024 && lane == 0) {
+    st[31] = __builtin_amdgcn_s_memtime();
+    unsigned long long *o = g_attn_stamps + ((size_t)blockIdx.x * 7 + wave) * 32;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) o[i] = st[i];
+  }
+#endif
   // O^T accumulator: col = query lr, row = dim (r&3) + 8*(r>>2) + 4*lh of each 32-dim tile -> 8-byte stores
   if (q < T) {
     const float inv = 1.f / l_run;
