@@ -14,7 +14,7 @@
 #define FA_NSTAGE 4
 #define FA_AHEAD 2      // key blocks the DMA runs ahead: slot kb-1 must survive iteration kb for the staggered waves
 #ifndef FA_STAGGER
-#define FA_STAGGER 1
+#define FA_STAGGER 0    // 1: waves 4-6 run PV(k-1) at the start of iteration k (measured: same time, 208-214 us either way)
 #endif
 #define FA_DMA_PER_WAVE 5   // ceil(32 DMA instructions per stage / 7 waves); surplus slots repeat an earlier one
 #define FA_THREADS (FA_WAVES * 64)
