@@ -1,4 +1,4 @@
-"""Run-to-run determinism of the refiner (two encoder heads on two streams) and of the attention core alone."""
+"""Tool: run-to-run determinism of the refiner (two encoder heads on two streams) and of the attention core alone."""
 import numpy as np, torch, sys
 sys.path.insert(0, '.')
 from tests import util
