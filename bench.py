@@ -130,7 +130,7 @@ def cpu_baseline():
   os.environ['OMP_NUM_THREADS'] = str(cores)
   torch.set_num_threads(cores)
   sc = util.scene(0)
-  n_s = 64
+  n_s = 126            # half of the 252-hypothesis workload: 10-15 s on 16 threads
   orc = OracleFoundationPose(sc['mt'], sc['diameter'], sc['center'], sc['grid'][:n_s], S.make_refine_state_dict(0),
                              S.make_score_state_dict(1), refine_cfg=dict(REFINE_DEFAULT), score_cfg=dict(SCORE_DEFAULT))
   t0 = time.time()
