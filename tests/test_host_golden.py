@@ -44,3 +44,70 @@ def test_guess_translation_host_branch(golden):
   # a mask over pixels with no usable depth
   c1 = FoundationPose.guess_translation(me, depth=np.zeros_like(golden['d2x_depth']), mask=golden['gt_mask'], K=S.YCB_K)
   np.testing.assert_array_equal(c1, np.zeros(3))
+
+
+def _rot_z(deg):
+  a = np.deg2rad(deg)
+  M = np.eye(4)
+  M[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+  return M
+
+
+def _geodesic_deg(Ra, Rb):
+  return np.degrees(np.arccos(np.clip((np.trace(Ra @ Rb.T) - 1) / 2, -1, 1)))
+
+
+def test_cluster_poses_native_with_symmetries():
+  """mycpp.cluster_poses (pybind_api.cpp:24-68) as native host code in the library (no kernel runs)
+  against the oracle's restatement, for the identity, a 4-fold and a 12-fold z symmetry, with and without the translation
+  gate; plus the algorithm's own invariants checked in float64 (kept poses are a subsequence starting with pose 0,
+  every later kept pose is >= the threshold from all earlier kept ones under every symmetry, every dropped pose is
+  within it of an earlier kept one).  The reference has no test for this routine: parity unpinned beyond the restatement."""
+  from oracle import geometry as G
+  rs = np.random.RandomState(4)
+  poses = []
+  for i in range(120):
+    M = np.eye(4)
+    M[:3, :3] = S.random_rotation(rs)
+    M[:3, 3] = rs.uniform(-0.05, 0.05, 3)
+    poses.append(M.astype(np.float32))
+  poses[7] = poses[3].copy()                                       # an exact duplicate
+  poses[9][:3, :3] = (poses[2] @ _rot_z(90).astype(np.float32))[:3, :3]; poses[9][:3, 3] = poses[2][:3, 3]   # equal to pose 2 under the 4-fold symmetry
+  for sym_deg, angle, dist in ((None, 30, 99999), ((0, 90, 180, 270), 30, 99999), (tuple(range(0, 360, 30)), 20, 99999), ((0, 180), 45, 0.04)):
+    sym = np.eye(4)[None] if sym_deg is None else np.stack([_rot_z(d) for d in sym_deg])
+    got = U.cluster_poses(angle, dist, poses, sym.astype(np.float32))
+    ref = G.cluster_poses(angle, dist, poses, sym)
+    assert len(got) == len(ref) and len(got) < len(poses)
+    for a, b in zip(got, ref):
+      np.testing.assert_array_equal(a, b)
+    idx = [next(i for i, p in enumerate(poses) if np.array_equal(p, g)) for g in got]
+    assert idx[0] == 0 and idx == sorted(idx)
+    if sym_deg is not None and 90 in sym_deg and dist > 1:
+      assert 9 not in idx and 7 not in idx
+    margin = 1e-3                                                  # degrees: float32 acos near the threshold
+    def near(i, j):
+      if np.linalg.norm(poses[i][:3, 3] - poses[j][:3, 3]) >= dist:
+        return None
+      return min(_geodesic_deg((poses[i].astype(np.float64) @ t)[:3, :3], poses[j][:3, :3].astype(np.float64)) for t in sym)
+    for n, i in enumerate(idx):
+      for j in idx[:n]:
+        d = near(i, j)
+        assert d is None or d >= angle - margin
+    for i in set(range(len(poses))) - set(idx):
+      ds = [near(i, j) for j in idx if j < i]
+      assert any(d is not None and d < angle + margin for d in ds)
+
+
+def test_rotation_grid_shrinks_under_symmetry():
+  """src/estimater.py:106-124 with symmetry_tfs: the 252-pose grid thins out when the object repeats every 90 degrees about
+  z; same poses from the package's native path and the oracle."""
+  from oracle import geometry as G
+  sym = np.stack([_rot_z(d) for d in (0, 90, 180, 270)])
+  ref = G.make_rotation_grid(symmetry_tfs=sym)
+  full = G.make_rotation_grid()
+  assert len(full) == 252 and 40 <= len(ref) < 252
+  views = U.sample_views_icosphere(n_views=40)
+  grid = [np.linalg.inv(v @ U.euler_matrix(0, 0, a)) for v in views for a in np.deg2rad(np.arange(0, 360, 60))]
+  got = np.asarray(U.cluster_poses(30, 99999, np.asarray(grid), sym.astype(np.float32)))
+  assert got.shape == ref.shape
+  np.testing.assert_allclose(got, ref, atol=1e-6)
