@@ -313,3 +313,39 @@ def test_predictors_other_config_branches(variant):
   s_ref = OP.score_predict(oscfg, ssd, sc['rgb'], depth, sc['K'], ref.numpy(), sc['mt'], sc['diameter'], chunk=8)
   np.testing.assert_allclose(s_got.cpu().numpy(), s_ref.numpy(), atol=2e-3)
   assert int(s_got.argmax()) == int(s_ref.argmax())
+
+
+def test_register_textured_symmetric_object():
+  """A textured mesh (uv + texture image path of make_mesh_tensors / the rasteriser, src/Utils.py:104-130,196-199) declared
+  2-fold symmetric about z (symmetry_tfs thins the rotation grid through the native cluster_poses, src/estimater.py:106-124),
+  through FoundationPose.register() against the oracle on the same grid: 24 hypotheses, 1 iteration."""
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.config import REFINE_DEFAULT, SCORE_DEFAULT
+  from foundationpose_amd.estimater import FoundationPose
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+  from foundationpose_amd.predict_score import ScorePredictor
+  from oracle import geometry as G
+  from oracle.predict import OracleFoundationPose
+  sc = util.scene(0, textured=True)
+  assert 'tex' in sc['mt'] and 'uv_idx' in sc['mt']
+  rsd, ssd = S.make_refine_state_dict(0), S.make_score_state_dict(1)
+  mesh = S.make_mustard_mesh(seed=0, textured=True)
+  sym = np.stack([np.eye(4), np.diag([-1.0, -1.0, 1.0, 1.0])])
+  np.random.seed(0)
+  est = FoundationPose(model_pts=mesh.vertices, model_normals=mesh.vertex_normals, mesh=mesh, symmetry_tfs=sym,
+                       refiner=PoseRefinePredictor(state_dict=rsd, cfg=REFINE_DEFAULT), scorer=ScorePredictor(state_dict=ssd, cfg=SCORE_DEFAULT))
+  grid_o = G.make_rotation_grid(symmetry_tfs=sym)
+  assert 40 <= len(grid_o) < 252 and est.rot_grid.shape == grid_o.shape
+  np.testing.assert_allclose(est.rot_grid.cpu().numpy(), grid_o, atol=1e-6)
+  est.diameter = sc['diameter']
+  est.rot_grid = est.rot_grid[:24].contiguous()
+  orc = OracleFoundationPose(sc['mt'], sc['diameter'], est.model_center, grid_o[:24], rsd, ssd, refine_cfg=dict(REFINE_DEFAULT),
+                             score_cfg=dict(SCORE_DEFAULT))
+  pose_g = est.register(K=sc['K'], rgb=sc['rgb'], depth=sc['depth'], ob_mask=sc['mask'], iteration=1)
+  pose_o = orc.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=1, chunk=12)
+  so, sg = np.asarray(orc.scores), est.scores.cpu().numpy()           # both sorted, best first
+  np.testing.assert_allclose(sg, so, atol=3e-3)
+  if so[0] - so[1] > 2e-3:                                             # top-1 / top-2 margin above the fp16 logit noise
+    assert int(est.best_id) == int(orc.best_id)
+    np.testing.assert_allclose(pose_g, pose_o, atol=1e-3)
+    np.testing.assert_allclose(est.poses[0].cpu().numpy(), np.asarray(orc.poses[0]), atol=1e-3)
