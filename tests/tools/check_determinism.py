@@ -1,6 +1,7 @@
 """Tool: run-to-run determinism of the refiner (two encoder heads on two streams) and of the attention core alone."""
-import numpy as np, torch, sys
-sys.path.insert(0, '.')
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import util
 from foundationpose_amd import synthetic as S
 from foundationpose_amd.config import REFINE_DEFAULT
