@@ -125,35 +125,22 @@ def bilateral_filter_depth(depth, radius=2, zfar=100, sigmaD=2, sigmaR=100000, d
 
 
 def depth2xyzmap(depth, K, uvs=None):
-  """src/Utils.py:399-417 (float64 arithmetic, float32 result).  numpy in -> numpy out on the host like the reference; a
-  device tensor in -> device tensor out through fp_depth2xyzmap_f64 (same arithmetic, no host copy)."""
-  if torch.is_tensor(depth) and depth.is_cuda:
-    if uvs is not None:
-      raise NotImplementedError('depth2xyzmap(uvs=...) on a device tensor')
-    d = depth.to(torch.float).contiguous()
-    ctx = _lib.Context.get(d.device)
-    out = torch.empty((d.shape[0], d.shape[1], 3), dtype=torch.float, device=d.device)
-    Kd, Kp = k_ptr(K)
-    check(lib().fp_depth2xyzmap_f64(ctx.handle, ptr(d), d.shape[0], d.shape[1], Kp, ptr(out), stream_ptr(d.device)))
-    return out
-  invalid_mask = (depth < 0.001)
-  H, W = depth.shape[:2]
-  if uvs is None:
-    vs, us = np.meshgrid(np.arange(0, H), np.arange(0, W), sparse=False, indexing='ij')
-    vs = vs.reshape(-1)
-    us = us.reshape(-1)
-  else:
-    uvs = uvs.round().astype(int)
-    us = uvs[:, 0]
-    vs = uvs[:, 1]
-  zs = depth[vs, us]
-  xs = (us - K[0, 2]) * zs / K[0, 0]
-  ys = (vs - K[1, 2]) * zs / K[1, 1]
-  pts = np.stack((xs.reshape(-1), ys.reshape(-1), zs.reshape(-1)), 1)
-  xyz_map = np.zeros((H, W, 3), dtype=np.float32)
-  xyz_map[vs, us] = pts
-  xyz_map[invalid_mask] = 0
-  return xyz_map
+  """src/Utils.py:399-417: back-projection in float64 arithmetic, one rounding to float32, depth < 1 mm -> 0.
+  Both input kinds run fp_depth2xyzmap_f64 on the device; a numpy image comes back as numpy (H,W,3) float32 like the
+  reference's, a device tensor stays on the device.  `uvs` (n,2) keeps only the listed (rounded) pixels, zeros elsewhere."""
+  as_numpy = not torch.is_tensor(depth)
+  d = torch.as_tensor(np.ascontiguousarray(depth) if as_numpy else depth, device='cuda').to(torch.float).contiguous()
+  ctx = _lib.Context.get(d.device)
+  H, W = d.shape[:2]
+  xyz = torch.empty((H, W, 3), dtype=torch.float, device=d.device)
+  Kd, Kp = k_ptr(K)
+  check(lib().fp_depth2xyzmap_f64(ctx.handle, ptr(d), H, W, Kp, ptr(xyz), stream_ptr(d.device)))
+  if uvs is not None:
+    px = torch.as_tensor(np.asarray(uvs).round().astype(np.int64), device=d.device)
+    keep = torch.zeros((H, W, 1), dtype=torch.bool, device=d.device)
+    keep[px[:, 1], px[:, 0]] = True
+    xyz = xyz * keep
+  return xyz.cpu().numpy() if as_numpy else xyz
 
 
 def mask_depth_stats(depth, mask, min_depth=0.001):
@@ -216,23 +203,29 @@ def projection_matrix_from_intrinsics(K, height, width, znear, zfar, window_coor
 
 
 def to_homo_torch(pts):
-  """src/Utils.py:520-526"""
-  ones = torch.ones((*pts.shape[:-1], 1), dtype=torch.float, device=pts.device)
-  return torch.cat((pts, ones), dim=-1)
+  """src/Utils.py:520-526: append w = 1."""
+  return torch.nn.functional.pad(pts.to(torch.float), (0, 1), value=1.0)
+
+
+def _apply_linear(vecs, mats, offset=None):
+  """Row-vector form of the reference's broadcasting rule (src/Utils.py:529-546): a stack of B transforms whose B is not
+  the number of vectors maps EVERY vector (result (B,N,3)); B equal to the vector count maps them one to one."""
+  one_to_one = mats.ndim >= 3 and mats.shape[-3] == vecs.shape[-2]
+  if one_to_one:
+    out = (vecs[..., None, :] @ mats.swapaxes(-1, -2))[..., 0, :]
+    return out if offset is None else out + offset
+  out = vecs @ mats.swapaxes(-1, -2)
+  return out if offset is None else out + offset[..., None, :]
 
 
 def transform_pts(pts, tf):
-  """src/Utils.py:529-536"""
-  if len(tf.shape) >= 3 and tf.shape[-3] != pts.shape[-2]:
-    tf = tf[..., None, :, :]
-  return (tf[..., :-1, :-1] @ pts[..., None] + tf[..., :-1, -1:])[..., 0]
+  """src/Utils.py:529-536: R p + t."""
+  return _apply_linear(pts, tf[..., :-1, :-1], tf[..., :-1, -1])
 
 
 def transform_dirs(dirs, tf):
-  """src/Utils.py:539-546"""
-  if len(tf.shape) >= 3 and tf.shape[-3] != dirs.shape[-2]:
-    tf = tf[..., None, :, :]
-  return (tf[..., :3, :3] @ dirs[..., None])[..., 0]
+  """src/Utils.py:539-546: R d."""
+  return _apply_linear(dirs, tf[..., :3, :3])
 
 
 def pose_to_egocentric_delta_pose(A_in_cam, B_in_cam):
@@ -241,11 +234,11 @@ def pose_to_egocentric_delta_pose(A_in_cam, B_in_cam):
 
 
 def egocentric_delta_pose_to_pose(A_in_cam, trans_delta, rot_mat_delta):
-  """src/Utils.py:848-855"""
-  B_in_cam = torch.eye(4, dtype=torch.float, device=A_in_cam.device)[None].expand(len(A_in_cam), -1, -1).contiguous()
-  B_in_cam[:, :3, 3] = A_in_cam[:, :3, 3] + trans_delta
-  B_in_cam[:, :3, :3] = rot_mat_delta @ A_in_cam[:, :3, :3]
-  return B_in_cam
+  """src/Utils.py:848-855: t' = t + dt, R' = dR R (the camera-frame update of the refiner)."""
+  n = len(A_in_cam)
+  top = torch.cat([rot_mat_delta @ A_in_cam[:, :3, :3], (A_in_cam[:, :3, 3] + trans_delta)[..., None]], dim=-1)
+  bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=torch.float, device=A_in_cam.device).expand(n, 1, 4)
+  return torch.cat([top.to(torch.float), bottom], dim=1)
 
 
 def compute_mesh_diameter(model_pts=None, mesh=None, n_sample=1000):
@@ -300,21 +293,23 @@ def sample_views_icosphere(n_views, subdivisions=None, radius=1):
       if verts.shape[0] >= n_views:
         break
       subdivision += 1
-  cam_in_obs = np.tile(np.eye(4)[None], (len(verts), 1, 1))
-  cam_in_obs[:, :3, 3] = verts
-  up = np.array([0, 0, 1])
-  z_axis = -cam_in_obs[:, :3, 3]
-  z_axis /= np.linalg.norm(z_axis, axis=-1).reshape(-1, 1)
-  x_axis = np.cross(up.reshape(1, 3), z_axis)
-  invalid = (x_axis == 0).all(axis=-1)
-  x_axis[invalid] = [1, 0, 0]
-  x_axis /= np.linalg.norm(x_axis, axis=-1).reshape(-1, 1)
-  y_axis = np.cross(z_axis, x_axis)
-  y_axis /= np.linalg.norm(y_axis, axis=-1).reshape(-1, 1)
-  cam_in_obs[:, :3, 0] = x_axis
-  cam_in_obs[:, :3, 1] = y_axis
-  cam_in_obs[:, :3, 2] = z_axis
-  return cam_in_obs
+  return _look_at_origin(verts)
+
+
+def _look_at_origin(eyes):
+  """Camera frames at `eyes` looking at the origin (src/Utils.py:491-507): z towards the origin, x = up x z with up = +z
+  of the object (x = +x of the object where that product vanishes, i.e. at the poles), y = z x x."""
+  eyes = np.asarray(eyes, dtype=np.float64)
+  fwd = -eyes / np.linalg.norm(eyes, axis=1, keepdims=True)
+  right = np.cross(np.broadcast_to([0.0, 0.0, 1.0], fwd.shape), fwd)
+  right[~right.any(axis=1)] = (1.0, 0.0, 0.0)
+  right /= np.linalg.norm(right, axis=1, keepdims=True)
+  down = np.cross(fwd, right)
+  down /= np.linalg.norm(down, axis=1, keepdims=True)
+  frames = np.zeros((len(eyes), 4, 4))
+  frames[:, :3, :] = np.stack([right, down, fwd, eyes], axis=2)
+  frames[:, 3, 3] = 1.0
+  return frames
 
 
 def euler_matrix(ai, aj, ak):

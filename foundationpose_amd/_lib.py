@@ -5,6 +5,7 @@ build command.  torch is used only for device memory and the current HIP stream.
 """
 import ctypes
 import os
+import weakref
 from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
 
 import numpy as np
@@ -56,6 +57,7 @@ _PROTOS = {
   'fp_net_destroy': (c_int, [c_void_p]),
   'fp_net_rot_dim': (c_int, [c_void_p]),
   'fp_refine_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_net_tokens': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_score_features': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_score_tail': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_pose_update': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p]),
@@ -190,18 +192,33 @@ class DeviceMesh:
       pass
 
 
-_mesh_cache = {}
+_mesh_cache = {}      # id(mesh_tensors['pos']) -> [(device, pos version, signature, DeviceMesh), ...]; dropped when that tensor dies
+
+
+def _mesh_signature(mesh_tensors):
+  """Identity + in-place version of every tensor of the dict.  The entries hold the tensors themselves (strong references,
+  except `pos`, whose death drops the entry), so an `id` cannot be recycled while its entry is alive."""
+  return tuple((k, v, v._version) for k, v in sorted(mesh_tensors.items()) if torch.is_tensor(v) and k != 'pos')
 
 
 def device_mesh(ctx, mesh_tensors):
-  """Cache the uploaded mesh per (device, pos storage)."""
-  key = (ctx.device_index, mesh_tensors['pos'].data_ptr(), mesh_tensors['faces'].data_ptr(), tuple(mesh_tensors['pos'].shape))
-  m = _mesh_cache.get(key)
-  if m is None:
-    if len(_mesh_cache) > 16:
-      _mesh_cache.clear()
-    m = DeviceMesh(ctx, mesh_tensors)
-    _mesh_cache[key] = m
+  """The fp_mesh of a reference-layout mesh_tensors dict, uploaded once per (device, set of tensor objects).  The cache is
+  keyed on the `pos` tensor OBJECT (its entry is dropped when the tensor dies - a dict built inside one call is not retained) and
+  checked against the identity and in-place version counter of every other tensor, so a re-coloured, re-textured or edited
+  mesh of the same size is uploaded again instead of being mistaken for the previous one at the same address."""
+  pos = mesh_tensors['pos']
+  sig = _mesh_signature(mesh_tensors)
+  entries = _mesh_cache.get(id(pos))
+  if entries is None:
+    entries = _mesh_cache[id(pos)] = []
+    weakref.finalize(pos, _mesh_cache.pop, id(pos), None)
+  for e in entries:
+    if e[0] == ctx.device_index and e[1] == pos._version and len(e[2]) == len(sig) and \
+       all(a[0] == b[0] and a[1] is b[1] and a[2] == b[2] for a, b in zip(e[2], sig)):
+      return e[3]
+  m = DeviceMesh(ctx, mesh_tensors)
+  entries[:] = [e for e in entries if e[0] != ctx.device_index][-3:]      # one live variant per device and pos object (+ a few devices)
+  entries.append((ctx.device_index, pos._version, sig, m))
   return m
 
 

@@ -89,6 +89,7 @@ extern "C" int fp_ctx_destroy(fp_ctx *ctx) {
     (void)hipEventDestroy(e.a);
     (void)hipEventDestroy(e.b);
   }
+  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   if (ctx->side_ready) {
     for (int i = 0; i < fp_ctx::NSIDE; ++i) {
       (void)hipStreamDestroy(ctx->side[i]);
@@ -136,8 +137,8 @@ static int prof_drain(fp_ctx *ctx) {
     p.total_ms += ms;
     p.flops += e.flops;
     p.launches += 1;
-    (void)hipEventDestroy(e.a);
-    (void)hipEventDestroy(e.b);
+    ctx->ev_pool.push_back(e.a);
+    ctx->ev_pool.push_back(e.b);
   }
   ctx->pending.clear();
   return FP_OK;

@@ -82,6 +82,7 @@ struct fp_ctx {
   bool prof = false;
   std::map<std::string, ProfEntry> prof_tab;
   std::vector<PendingEvent> pending;
+  std::vector<hipEvent_t> ev_pool;   // recycled timing events: a profiled launch costs two hipEventRecord, no create / destroy
   int num_cu = 256;
   void *zero_page = nullptr;   // 4 KB of zeros: DMA source for out-of-image taps
   // side streams for the per-object stages (crop window, render, observed crop) of a multi-object pass: with 8 objects
@@ -150,12 +151,22 @@ struct ProfScope {
   bool on;
   ProfScope(fp_ctx *c, hipStream_t st, const char *cls, double flops) : ctx(c), s(st), on(c && c->prof) {
     if (on) {
-      (void)hipEventCreate(&ev.a);
-      (void)hipEventCreate(&ev.b);
+      ev.a = take_event();
+      ev.b = take_event();
       ev.cls = cls;
       ev.flops = flops;
       (void)hipEventRecord(ev.a, s);
     }
+  }
+  hipEvent_t take_event() {
+    hipEvent_t e = nullptr;
+    if (!ctx->ev_pool.empty()) {
+      e = ctx->ev_pool.back();
+      ctx->ev_pool.pop_back();
+    } else {
+      (void)hipEventCreate(&e);
+    }
+    return e;
   }
   ~ProfScope() {
     if (on) {

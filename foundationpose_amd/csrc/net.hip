@@ -427,6 +427,24 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
   return rc;
 }
 
+extern "C" int fp_net_tokens(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, void *d_tokens, void *stream) {
+  FP_REQUIRE(ctx && net && d_net_in && d_tokens, "fp_net_tokens: null argument");
+  FP_REQUIRE(N >= 0, "fp_net_tokens: N<0");
+  if (N == 0) return FP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(N)));
+  const size_t mark = ctx->arena.off;
+  f16 *tok = nullptr;
+  const f16 *in = (const f16 *)d_net_in;
+  int rc = run_trunk(ctx, net, in, in + (size_t)N * 160 * 160 * 8, N, &tok, s);
+  if (rc == FP_OK && hipMemcpyAsync(d_tokens, tok, (size_t)N * 400 * 512 * sizeof(f16), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+    fp_set_error("fp_net_tokens: copy failed");
+    rc = FP_EHIP;
+  }
+  ctx->arena.off = mark;
+  return rc;
+}
+
 extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, void *stream) {
   FP_REQUIRE(ctx && net && d_net_in && d_feats, "fp_score_features: null argument");
   FP_REQUIRE(net->kind == FP_NET_SCORE, "fp_score_features: not a ScoreNetMultiPair");

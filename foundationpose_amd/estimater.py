@@ -198,3 +198,25 @@ class FoundationPose:
       extra['vis'] = vis
     self.pose_last = pose
     return (pose @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)
+
+  def track_multi(self, rgb, depth, K, iteration, n_hypotheses=64, trans_sigma=0.003, rot_sigma_deg=1.5, extra={}):
+    """Multi-hypothesis tracking (BASELINE.json configs[4]; a build extension, the reference's track_one refines one pose
+    and never scores): the previous pose and n-1 fixed seeded perturbations of it (tracking.tracking_hypotheses) are refined
+    together, scored by ScoreNet, and the best-scoring refined pose becomes `pose_last`.  Same prelude and return value as
+    track_one; `self.poses` / `self.scores` hold all hypotheses of the frame in hypothesis order, `self.best_id` the winner."""
+    from .tracking import tracking_hypotheses
+    if self.pose_last is None:
+      logging.info("Please init pose by register first")
+      raise RuntimeError
+    depth = torch.as_tensor(depth, device='cuda', dtype=torch.float)
+    rgb = torch.as_tensor(np.ascontiguousarray(rgb) if isinstance(rgb, np.ndarray) else rgb, device='cuda').to(torch.float)
+    depth = U.bilateral_filter_depth(U.erode_depth(depth, radius=2, device='cuda'), radius=2, device='cuda')
+    xyz_map = U.depth2xyzmap_batch(depth[None], torch.as_tensor(K, dtype=torch.float, device='cuda')[None], zfar=np.inf)[0]
+    hyp = tracking_hypotheses(self.pose_last.reshape(4, 4), n_hypotheses, trans_sigma, rot_sigma_deg)
+    shared = dict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K, glctx=self.glctx, mesh_diameter=self.diameter)
+    refined, _ = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
+    scores, _ = self.scorer.predict(ob_in_cams=refined, normal_map=None, **shared)
+    self.best_id = scores.argmax()
+    self.poses, self.scores = refined, scores
+    self.pose_last = refined[self.best_id]
+    return (self.pose_last @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)

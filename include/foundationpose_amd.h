@@ -114,6 +114,10 @@ int fp_net_rot_dim(const fp_net *net);   /* 3 (axis_angle) or 6 (6d), from rot_h
 /* a15: RefineNet.forward.  d_net_in: fp16 net tensor [2N][160][160][8], A = first N images, B = last N. */
 int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans /* N*3 */,
                       float *d_rot /* N*rot_dim */, void *stream);
+/* The shared trunk alone (encodeA/encodeAB | encoderA/encoderAB + pos_embed: refine_network.py:79-88, score_network.py:66-72):
+ * d_tokens receives the (N,400,512) fp16 token tensor both heads read.  Exported for the parity tests, which compare it with
+ * the reference module's encodeAB output. */
+int fp_net_tokens(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, void *d_tokens /* fp16 N*400*512 */, void *stream);
 /* a19: ScoreNetMultiPair.extract_feat -> d_feats N*512 fp32 */
 int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, void *stream);
 /* a19/a20: att_cross + linear over `groups` objects of L hypotheses each (score_network.py:82-88),

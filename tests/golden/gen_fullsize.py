@@ -1,0 +1,183 @@
+"""Generate tests/golden/fullsize.npz: the CPU ORACLE's results at BASELINE.json's full sizes, so that the GPU tests can
+assert the acceptance criterion (refined 4x4 poses within 1e-3, identical argmax) where it is hardest: 252 hypotheses x
+5 recurrent iterations (configs[1]), the four objects of configs[3], the 32-hypothesis cases of configs[0] and 10 frames
+of configs[4] (track_one and the 64-hypothesis tracking mode).
+
+Runs in the build container on the CPU only (oracle/ + foundationpose_amd.synthetic; it does NOT need /root/reference:
+the oracle's networks are pinned to the reference's modules by tests/golden/gen_golden.py).  Cases are defined in
+tests/cases.py, shared with the tests.
+
+  python tests/golden/gen_fullsize.py feats     # heavy (~12 min on 8 cores): oracle refine + ScoreNet features per case,
+                                                # cached in /tmp/fp_fullsize_feats.npz
+  python tests/golden/gen_fullsize.py track     # configs[4] frames (run after the tail seed is fixed: the 64-hypothesis chain
+                                                # follows the scorer's choice)
+  python tests/golden/gen_fullsize.py tail      # search the ScoreNet tail seed (att_cross + linear; the trunk and the
+                                                # per-hypothesis features do not depend on it) that maximises the smallest
+                                                # top-1 / top-2 logit margin over all cases; prints the ranking
+  python tests/golden/gen_fullsize.py write     # fixture with synthetic.py's current default tail seed
+
+The chosen tail seed is the default of foundationpose_amd.synthetic.make_score_state_dict; fullsize.npz records, per case,
+the oracle's margin and logit spread, and the tests assert margin >= 20 x the fp16 logit noise they measure.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..'))
+sys.path.insert(0, REPO)
+CACHE = '/tmp/fp_fullsize_feats.npz'
+
+
+def oracle_case(name, out):
+  """Refined poses per iteration (hypothesis order) + fp32 ScoreNet features on the final poses."""
+  from foundationpose_amd import synthetic as S
+  from oracle import nets, predict as OP
+  from tests import cases
+  c = cases.case(name)
+  sc = c['sc']
+  rsd = S.make_refine_state_dict(**c['refine_sd_kw'])
+  ssd = S.make_score_state_dict(**c['score_sd_kw'])
+  rcfg = dict(OP.DEFAULT_REFINE_CFG, **{k: c['refine_cfg'][k] for k in ('normalize_xyz', 'rot_rep', 'use_BN', 'crop_ratio') if k in c['refine_cfg']})
+  scfg = dict(OP.DEFAULT_SCORE_CFG, **{k: c['score_cfg'][k] for k in ('normalize_xyz', 'use_BN', 'crop_ratio') if k in c['score_cfg']})
+  t0 = time.time()
+  trace = []
+  poses = OP.refine_predict(rcfg, rsd, sc['rgb'], c['depth'], sc['K'], c['poses0'], c['xyz_map'], sc['mt'], sc['diameter'],
+                            iteration=c['iteration'], chunk=16, trace=trace)
+  per_iter = [t['poseA'].numpy() for t in trace[1:]] + [poses.numpy()]
+  rgb_t = torch.as_tensor(sc['rgb'], dtype=torch.float32)
+  depth_t = torch.as_tensor(c['depth'], dtype=torch.float32)
+  pd = OP.make_crop_data_batch_score(scfg, poses.numpy(), sc['mt'], rgb_t, depth_t, sc['K'], sc['diameter'])
+  A = torch.cat([pd['rgbAs'], pd['xyz_mapAs']], dim=1).float()
+  B = torch.cat([pd['rgbBs'], pd['xyz_mapBs']], dim=1).float()
+  feats = torch.cat([nets.score_extract_feat(ssd, A[i:i + 16], B[i:i + 16], scfg['use_BN']) for i in range(0, len(A), 16)], 0)
+  out[f'{name}/poses0'] = c['poses0']
+  out[f'{name}/poses_iter'] = np.stack(per_iter).astype(np.float32)
+  out[f'{name}/feats'] = feats.numpy()
+  print(f'{name}: {len(c["poses0"])} hyp x {c["iteration"]} iterations + features in {time.time() - t0:.0f} s', flush=True)
+
+
+def oracle_tracking(out, n_frames=10):
+  """configs[4]: (a) track_one, 1 hypothesis x 2 iterations per frame, chained; (b) 64-hypothesis mode: the previous pose
+  and 63 seeded perturbations of it, refine x2 + score, best one is kept (frame f starts from the ORACLE's frame f-1
+  result on both sides of the test, so one near-tie cannot derail the rest of the sequence)."""
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.tracking import tracking_hypotheses
+  from oracle import geometry as G, nets, predict as OP
+  from tests import cases
+  sc, frames = cases.tracking_frames(n_frames)
+  rsd, ssd = S.make_refine_state_dict(cases.REFINE_SEED), S.make_score_state_dict(cases.SCORE_SEED)
+  rcfg, scfg = dict(OP.DEFAULT_REFINE_CFG), dict(OP.DEFAULT_SCORE_CFG)
+  t0 = time.time()
+  start = torch.as_tensor(frames[0]['gt_pose']).clone()
+  start[:3, 3] += torch.tensor([0.003, -0.002, 0.004])          # tracker starts slightly off the true pose
+  out['trk/start'] = start.numpy()
+  one, multi_in, multi_poses, multi_feats = [], [], [], []
+  p1 = start.clone().reshape(1, 4, 4)
+  p64 = start.clone()
+  for fr in frames:
+    depth = G.bilateral_filter_depth(G.erode_depth(fr['depth']))
+    K32 = torch.as_tensor(np.asarray(fr['K']), dtype=torch.float32)
+    xyz = G.depth2xyzmap_batch(torch.as_tensor(depth)[None], K32[None], zfar=np.inf)[0]
+    p1 = OP.refine_predict(rcfg, rsd, fr['rgb'], depth, fr['K'], p1.numpy(), xyz, sc['mt'], sc['diameter'], iteration=2, chunk=16)
+    one.append(p1[0].numpy())
+    hyp = tracking_hypotheses(p64, 64)
+    multi_in.append(hyp.numpy())
+    refined = OP.refine_predict(rcfg, rsd, fr['rgb'], depth, fr['K'], hyp.numpy(), xyz, sc['mt'], sc['diameter'], iteration=2, chunk=16)
+    pd = OP.make_crop_data_batch_score(scfg, refined.numpy(), sc['mt'], torch.as_tensor(fr['rgb'], dtype=torch.float32),
+                                       torch.as_tensor(depth), fr['K'], sc['diameter'])
+    A = torch.cat([pd['rgbAs'], pd['xyz_mapAs']], dim=1).float()
+    B = torch.cat([pd['rgbBs'], pd['xyz_mapBs']], dim=1).float()
+    feats = torch.cat([nets.score_extract_feat(ssd, A[i:i + 16], B[i:i + 16], True) for i in range(0, 64, 16)], 0)
+    logits = nets.score_tail(ssd, feats, 64).reshape(-1)
+    p64 = refined[int(logits.argmax())]
+    multi_poses.append(refined.numpy())
+    multi_feats.append(feats.numpy())
+  out['trk/one'] = np.stack(one).astype(np.float32)
+  out['trk/multi_in'] = np.stack(multi_in).astype(np.float32)
+  out['trk/multi_poses'] = np.stack(multi_poses).astype(np.float32)
+  out['trk/multi_feats'] = np.stack(multi_feats).astype(np.float32)
+  print(f'tracking: {n_frames} frames in {time.time() - t0:.0f} s (NOTE: the 64-hypothesis chain depends on the tail seed; rerun "feats" '
+        f'after changing it)', flush=True)
+
+
+def logits_of(ssd, feats):
+  from oracle import nets
+  return nets.score_tail(ssd, torch.as_tensor(feats), len(feats)).reshape(-1).numpy()
+
+
+def margin_stats(lg):
+  o = np.sort(lg)[::-1]
+  return float(o[0] - o[1]), float(lg.std())
+
+
+def stage_feats():
+  from tests import cases
+  torch.set_num_threads(os.cpu_count())
+  out = {}
+  for name in cases.REGISTER_CASES:
+    oracle_case(name, out)
+  np.savez(CACHE, **out)
+  print('cached', CACHE)
+
+
+def stage_track():
+  torch.set_num_threads(os.cpu_count())
+  out = dict(np.load(CACHE))
+  oracle_tracking(out)
+  np.savez(CACHE, **out)
+
+
+def stage_tail(n_seeds=4000):
+  from foundationpose_amd import synthetic as S
+  from tests import cases
+  z = np.load(CACHE)
+  names = cases.REGISTER_CASES
+  groups = [z[f'{n}/feats'] for n in names]
+  base = S.make_score_state_dict(cases.SCORE_SEED)
+  res = []
+  for seed in range(n_seeds):
+    ssd = dict(base)
+    ssd.update({k: v for k, v in S.make_score_state_dict(cases.SCORE_SEED, tail_seed=seed, tail_only=True).items()})
+    worst = 1e9
+    for f in groups:                                       # (the tracking chain's features depend on the seed: checked after)
+      m, sp = margin_stats(logits_of(ssd, f))
+      worst = min(worst, m / sp)
+    res.append((worst, seed))
+  res.sort(reverse=True)
+  print('best (min over cases of margin / logit std, tail seed):', res[:10])
+
+
+def stage_write():
+  from foundationpose_amd import synthetic as S
+  from tests import cases
+  z = np.load(CACHE)
+  ssd = S.make_score_state_dict(cases.SCORE_SEED)
+  out = {}
+  for name in cases.REGISTER_CASES:
+    lg = logits_of(ssd, z[f'{name}/feats'])
+    m, sp = margin_stats(lg)
+    out[f'{name}/poses_iter'] = z[f'{name}/poses_iter']
+    out[f'{name}/logits'] = lg.astype(np.float32)
+    out[f'{name}/argmax'] = np.array(int(lg.argmax()))
+    out[f'{name}/margin'] = np.array(m)
+    out[f'{name}/spread'] = np.array(sp)
+    print(f'{name}: argmax {int(lg.argmax())}, margin {m:.3e}, spread {sp:.3e}, margin/spread {m / sp:.2f}')
+  out['c1/feats'] = z['c1/feats']
+  for k in ('trk/start', 'trk/one', 'trk/multi_in', 'trk/multi_poses'):
+    out[k] = z[k]
+  lgs = np.stack([logits_of(ssd, f) for f in z['trk/multi_feats']])
+  out['trk/multi_logits'] = lgs.astype(np.float32)
+  ms = [margin_stats(l) for l in lgs]
+  out['trk/multi_margin'] = np.array([m for m, _ in ms])
+  print('tracking margins / spread:', [f'{m / s:.2f}' for m, s in ms], 'argmax', lgs.argmax(1))
+  path = os.path.join(HERE, 'fullsize.npz')
+  np.savez_compressed(path, **out)
+  print('wrote', path, f'{os.path.getsize(path) / 1e6:.2f} MB')
+
+
+if __name__ == '__main__':
+  {'feats': stage_feats, 'track': stage_track, 'tail': stage_tail, 'write': stage_write}[sys.argv[1]]()

@@ -67,20 +67,9 @@ class Cfg(dict):
   __getattr__ = dict.__getitem__
 
 
-def net_inputs(seed, n):
-  """Network-like inputs: rgb in [0,1], xyz in [-2,2] with ~40 % exact zeros (masked background)."""
-  rs = np.random.RandomState(seed)
-  out = []
-  for _ in range(2):
-    rgb = rs.uniform(0, 1, (n, 3, 160, 160)).astype(np.float32)
-    xyz = (rs.randn(n, 3, 160, 160) * 0.5).astype(np.float32)
-    xyz[np.broadcast_to(rs.uniform(size=(n, 1, 160, 160)) < 0.4, xyz.shape)] = 0
-    out.append(torch.from_numpy(np.concatenate([rgb, xyz], 1)))
-  return out
-
-
 def main():
   from foundationpose_amd import synthetic as S
+  from tests.util import net_inputs
   U, RefineNet, ScoreNetMultiPair, PositionalEmbedding, BatchPoseData, E = import_reference()
   torch.set_num_threads(8)
   out = {}
@@ -99,7 +88,7 @@ def main():
   out['refine_keys_ok'] = np.array(1)
   net.encodeA[3].register_forward_hook(hook('encA3'))
   net.encodeAB[4].register_forward_hook(hook('encAB4'))
-  A, B = net_inputs(11, 2)
+  A, B = net_inputs(11, 8)
   with torch.no_grad():
     o = net(A, B)
   out['refine_trans'] = o['trans'].numpy()
@@ -112,7 +101,7 @@ def main():
   net2 = RefineNet(cfg=cfg2, c_in=6).eval()
   sd2 = S.make_refine_state_dict(seed=2, use_bn=False, rot_out_dim=6)
   net2.load_state_dict(sd2, strict=True)
-  A2, B2 = net_inputs(12, 1)
+  A2, B2 = net_inputs(12, 4)
   with torch.no_grad():
     o2 = net2(A2, B2)
   out['refine_nobn_trans'] = o2['trans'].numpy()
@@ -122,14 +111,16 @@ def main():
   snet = ScoreNetMultiPair(cfg=Cfg(use_BN=True), c_in=6).eval()
   ssd = S.make_score_state_dict(seed=1)
   snet.load_state_dict(ssd, strict=True)
-  A3, B3 = net_inputs(13, 4)
+  A3, B3 = net_inputs(13, 8)
+  snet.encoderAB[4].register_forward_hook(hook('s_encAB4'))
   with torch.no_grad():
     feats = snet.extract_feat(A3, B3)
-    so = snet(A3, B3, L=4)
-    so2 = snet(A3, B3, L=2)        # two "objects" of two hypotheses each (bs=2 groups)
+    so = snet(A3, B3, L=8)
+    so2 = snet(A3, B3, L=4)        # two "objects" of four hypotheses each (bs=2 groups)
   out['score_feats'] = feats.numpy()
-  out['score_logit_L4'] = so['score_logit'].numpy()
-  out['score_logit_L2'] = so2['score_logit'].numpy()
+  out['score_logit_L8'] = so['score_logit'].numpy()
+  out['score_logit_L4'] = so2['score_logit'].numpy()
+  out['score_encAB4_sub'] = taps['s_encAB4'][:, ::64, ::4, ::4].numpy()
 
   # ---- PositionalEmbedding buffer -----------------------------------------------------------------
   pe = PositionalEmbedding(d_model=512, max_len=400).pe

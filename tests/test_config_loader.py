@@ -1,0 +1,115 @@
+"""The upstream-checkpoint path: weights/<run>/model_best.pth + config.yml, as the reference's
+predictors read them with no constructor arguments (learning/training/predict_pose_refine.py:97-141,
+predict_score.py:120-154).  CPU part: the loader itself; the GPU part builds both predictors through it."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from foundationpose_amd import config as C
+from foundationpose_amd import synthetic as S
+
+REFINE_RUN, SCORE_RUN = '2023-10-28-18-33-37', '2024-01-11-20-02-45'     # predict_pose_refine.py:97, predict_score.py:120
+
+
+def write_run(root, run, state_dict, cfg, wrap=True):
+  d = os.path.join(root, run)
+  os.makedirs(d, exist_ok=True)
+  torch.save({'model': state_dict, 'epoch': 7} if wrap else state_dict, os.path.join(d, 'model_best.pth'))
+  with open(os.path.join(d, 'config.yml'), 'w') as f:
+    yaml.safe_dump(cfg, f)
+  return d
+
+
+def test_load_run_dir_unwraps_and_reads_yaml(tmp_path):
+  sd = {'a.weight': torch.arange(6.).reshape(2, 3), 'a.num_batches_tracked': torch.tensor(3)}
+  cfg = dict(input_resize=[160, 160], zfar='inf', rot_normalizer=0.349)
+  write_run(str(tmp_path), 'runA', sd, cfg, wrap=True)
+  got, file_cfg = C.load_run_dir('runA', str(tmp_path))
+  assert sorted(got) == sorted(sd) and torch.equal(got['a.weight'], sd['a.weight'])      # ['model'] unwrapped
+  assert file_cfg['zfar'] == 'inf' and file_cfg['input_resize'] == [160, 160]
+  assert file_cfg['ckpt_dir'].endswith(os.path.join('runA', 'model_best.pth'))
+  write_run(str(tmp_path), 'runB', sd, cfg, wrap=False)                                  # a bare state_dict loads too
+  got2, _ = C.load_run_dir('runB', str(tmp_path))
+  assert torch.equal(got2['a.weight'], sd['a.weight'])
+  with pytest.raises(FileNotFoundError, match='FOUNDATIONPOSE_WEIGHTS'):
+    C.load_run_dir('missing', str(tmp_path))
+
+
+def test_weights_root_env(tmp_path, monkeypatch):
+  monkeypatch.setenv('FOUNDATIONPOSE_WEIGHTS', str(tmp_path))
+  assert C.weights_root_default() == str(tmp_path)
+  monkeypatch.delenv('FOUNDATIONPOSE_WEIGHTS')
+  assert C.weights_root_default().endswith('weights')
+
+
+def test_checkpoint_with_python_objects_is_refused(tmp_path):
+  """Only loaders that execute nothing from the file: a pickle carrying an arbitrary object must not load."""
+  d = tmp_path / 'evil'
+  d.mkdir()
+
+  class Payload:
+    def __reduce__(self):
+      return (os.system, ('true',))
+  torch.save({'model': {'w': torch.zeros(1)}, 'extra': Payload()}, str(d / 'model_best.pth'))
+  (d / 'config.yml').write_text('input_resize: [160, 160]\n')
+  with pytest.raises(Exception):
+    C.load_run_dir('evil', str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_predictors_built_from_run_dirs_match_injected_ones(tmp_path, monkeypatch):
+  """PoseRefinePredictor() / ScorePredictor() with NO arguments: FOUNDATIONPOSE_WEIGHTS -> load_run_dir -> ['model']
+  unwrap -> back-compat defaults -> `zfar: inf` string -> DeviceNet.  Outputs must equal, bit for bit, those of predictors
+  given the same state_dict / config directly.  Case A spells every key (BatchNorm variant); case B omits every key that has
+  a back-compat default (so use_BN=False, normalize_xyz=False, crop_ratio=1.2, trans_rep='tracknet' come from the defaults)."""
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+  from foundationpose_amd.predict_score import ScorePredictor
+  from tests import util
+  from oracle import geometry as G
+  sc = util.scene(0)
+  depth = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+  xyz_map = G.depth2xyzmap(depth, sc['K'])
+  poses = util.hypotheses(sc, 6, jitter_seed=3)
+  mt = util.to_dev(sc['mt'])
+  kw = dict(rgb=sc['rgb'], depth=depth, K=sc['K'], mesh_tensors=mt, mesh_diameter=sc['diameter'])
+  cases = {
+    'A': dict(rsd=S.make_refine_state_dict(0), ssd=S.make_score_state_dict(1),
+              ryml=dict(C.REFINE_DEFAULT, zfar='inf'), syml=dict(C.SCORE_DEFAULT, zfar='inf'),
+              rcfg=dict(C.REFINE_DEFAULT), scfg=dict(C.SCORE_DEFAULT)),
+    'B': dict(rsd=S.make_refine_state_dict(seed=2, use_bn=False, rot_out_dim=6), ssd=S.make_score_state_dict(seed=3, use_bn=False),
+              ryml=dict(input_resize=[160, 160], c_in=6, rot_rep='6d', trans_normalizer=[0.02, 0.02, 0.05], rot_normalizer=0.3490659),
+              syml=dict(input_resize=[160, 160], c_in=6),
+              rcfg=dict(C.REFINE_DEFAULT, use_BN=False, normalize_xyz=False, rot_rep='6d', crop_ratio=1.2),
+              scfg=dict(C.SCORE_DEFAULT, use_BN=False, normalize_xyz=False, crop_ratio=1.2)),
+  }
+  for name, c in cases.items():
+    root = str(tmp_path / name)
+    write_run(root, REFINE_RUN, c['rsd'], c['ryml'], wrap=True)
+    write_run(root, SCORE_RUN, c['ssd'], c['syml'], wrap=(name == 'A'))
+    monkeypatch.setenv('FOUNDATIONPOSE_WEIGHTS', root)
+    r_file, s_file = PoseRefinePredictor(), ScorePredictor()
+    assert r_file.run_name == REFINE_RUN and s_file.run_name == SCORE_RUN and r_file.cfg['ckpt_dir'].startswith(root)
+    if name == 'A':
+      assert r_file.cfg['zfar'] == np.inf                       # 'inf' string -> np.inf (predict_pose_refine.py:128-129)
+    else:
+      assert r_file.cfg['use_BN'] is False and r_file.cfg['normalize_xyz'] is False and r_file.cfg['crop_ratio'] == 1.2
+      assert r_file.cfg['c_in'] == 6 and r_file.cfg['zfar'] == 3 and s_file.cfg['zfar'] == np.inf
+    r_inj = PoseRefinePredictor(state_dict=c['rsd'], cfg=c['rcfg'])
+    s_inj = ScorePredictor(state_dict=c['ssd'], cfg=c['scfg'])
+    p_file, _ = r_file.predict(ob_in_cams=poses, xyz_map=xyz_map, iteration=2, **kw)
+    p_inj, _ = r_inj.predict(ob_in_cams=poses, xyz_map=xyz_map, iteration=2, **kw)
+    assert torch.equal(p_file, p_inj) and float((p_file.cpu() - torch.as_tensor(poses)).abs().max()) > 1e-4
+    sc_file, _ = s_file.predict(ob_in_cams=p_file, **kw)
+    sc_inj, _ = s_inj.predict(ob_in_cams=p_inj, **kw)
+    assert torch.equal(sc_file, sc_inj)
+  # keys the reference reads WITHOUT a default must be present (predict_pose_refine.py:166,178,221)
+  root = str(tmp_path / 'C')
+  bad = dict(cases['A']['ryml'])
+  bad.pop('rot_normalizer')
+  write_run(root, REFINE_RUN, cases['A']['rsd'], bad)
+  monkeypatch.setenv('FOUNDATIONPOSE_WEIGHTS', root)
+  with pytest.raises(KeyError, match='rot_normalizer'):
+    PoseRefinePredictor()

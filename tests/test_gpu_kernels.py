@@ -380,6 +380,12 @@ def test_register_prelude_on_device(sc, fp, golden):
   d_dev = torch.from_numpy(depth).cuda()
   xyz = U.depth2xyzmap(d_dev, K)
   assert xyz.is_cuda and np.array_equal(xyz.cpu().numpy(), golden['d2x_xyz'])            # bit-exact (float64 math, one rounding)
+  xyz_np = U.depth2xyzmap(depth, K)                                                      # numpy in -> numpy out, same kernel
+  assert isinstance(xyz_np, np.ndarray) and xyz_np.dtype == np.float32 and np.array_equal(xyz_np, golden['d2x_xyz'])
+  uvs = np.array([[3, 2], [10, 7]])
+  only = U.depth2xyzmap(depth, K, uvs=uvs)
+  assert np.array_equal(only[2, 3], golden['d2x_xyz'][2, 3]) and np.array_equal(only[7, 10], golden['d2x_xyz'][7, 10])
+  assert np.count_nonzero(only.any(-1)) <= 2
   dummy = type('E', (), {})()
   t = FoundationPose.guess_translation(dummy, depth=d_dev, mask=mask, K=K)
   np.testing.assert_allclose(t, golden['gt_center'], rtol=0, atol=1e-12)

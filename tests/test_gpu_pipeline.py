@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from tests import util
-from tests.test_oracle_golden import net_inputs
+from tests.util import net_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -38,14 +38,52 @@ def _refine_gpu(ng, net, A, B):
   return trans.cpu(), rot.cpu()
 
 
+def _tokens_gpu(ng, net, A, B):
+  """Trunk output of the HIP network as the reference's encodeAB[4] activation (N,512,20,20): tokens minus pos_embed."""
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  n = len(A)
+  x = to_net_tensor(A, B)
+  tok = torch.empty((n, 400, 512), dtype=torch.float16, device='cuda')
+  check(lib().fp_net_tokens(ng['ctx'].handle, net.handle, ptr(x), n, ptr(tok), stream_ptr()))
+  feat = tok.float().cpu() - S.positional_embedding()[:, :400]
+  return feat.permute(0, 2, 1).reshape(n, 512, 20, 20)
+
+
+def assert_tracks_input(got, want, rel, what):
+  """`got` must follow the INPUT-DEPENDENT part of the reference output `want` (samples along axis 0): after removing each
+  column's mean over the samples, the error has to stay below `rel` x that column's spread over the samples - a kernel that
+  ignored, permuted or mixed up its inputs has an error of the order of the spread itself.  The common part (the mean over
+  samples) has to agree to half a spread."""
+  got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+  got, want = got.reshape(len(got), -1), want.reshape(len(want), -1)
+  spread = want.std(0)
+  dm = np.abs((got - got.mean(0)) - (want - want.mean(0))).max(0)
+  common = np.abs(got.mean(0) - want.mean(0))
+  live = spread > 0.05 * spread.mean()          # (sub-sampled activation taps hold a few dead / constant channels)
+  print(f'{what}: spread over samples min {spread[live].min():.2e} mean {spread.mean():.2e}; de-meaned error max {dm.max():.2e} '
+        f'(worst ratio {np.max(dm[live] / spread[live]):.3f}); common-part error max {common.max():.2e}')
+  assert (dm[live] <= rel * spread[live]).all(), f'{what}: does not follow its input'
+  assert dm.max() <= rel * spread.mean() * 4 and (common <= 0.5 * np.maximum(spread, spread.mean())).all(), what
+
+
 def test_refine_net_vs_reference_golden(nets_gpu, golden):
-  """The HIP RefineNet against the outputs of the REFERENCE's own nn.Module (fp32, CPU) on the
-  golden inputs.  fp16 operands / fp32 accumulate through 17 GEMM layers: the outputs are O(0.1);
-  tolerance 2e-3 absolute (the reference itself runs this net under fp16 autocast)."""
-  A, B = net_inputs(11, 2)
+  """The HIP RefineNet against the outputs of the REFERENCE's own nn.Module (fp32, CPU) on 8 golden input pairs that
+  differ the way crops do (tests/util.py:net_inputs): trunk activations (encodeAB[4] tap) and both head outputs must follow
+  the input-dependent part of the reference's to 10 % of its spread over the samples (fp16 operands / fp32 accumulation
+  through 17 GEMM layers; the reference itself runs this net under fp16 autocast)."""
+  A, B = net_inputs(11, 8)
+  feat = _tokens_gpu(nets_gpu, nets_gpu['rnet'], A, B)
+  assert_tracks_input(feat[:, ::64, ::4, ::4].numpy(), golden['refine_encAB4_sub'], 0.1, 'encodeAB[4] tap')
   trans, rot = _refine_gpu(nets_gpu, nets_gpu['rnet'], A, B)
+  assert_tracks_input(trans.numpy(), golden['refine_trans'], 0.1, 'trans head')
+  assert_tracks_input(rot.numpy(), golden['refine_rot'], 0.1, 'rot head')
   np.testing.assert_allclose(trans.numpy(), golden['refine_trans'], atol=2e-3)
   np.testing.assert_allclose(rot.numpy(), golden['refine_rot'], atol=2e-3)
+  # permuting the inputs permutes the outputs (and the permuted outputs differ from the unpermuted ones)
+  perm = [3, 0, 7, 1, 6, 2, 5, 4]
+  tp, rp = _refine_gpu(nets_gpu, nets_gpu['rnet'], A[perm], B[perm])
+  assert torch.equal(tp, trans[perm]) and torch.equal(rp, rot[perm]) and not torch.equal(tp, trans)
 
 
 def test_refine_net_no_bn_6d_vs_golden(nets_gpu, golden):
@@ -53,30 +91,39 @@ def test_refine_net_no_bn_6d_vs_golden(nets_gpu, golden):
   sd = S.make_refine_state_dict(seed=2, use_bn=False, rot_out_dim=6)
   net = _lib.DeviceNet(nets_gpu['ctx'], _lib.FP_NET_REFINE, sd, use_bn=False)
   assert net.rot_dim == 6
-  A, B = net_inputs(12, 1)
+  A, B = net_inputs(12, 4)
   trans, rot = _refine_gpu(nets_gpu, net, A, B)
+  assert_tracks_input(trans.numpy(), golden['refine_nobn_trans'], 0.15, 'no-BN trans head')
+  assert_tracks_input(rot.numpy(), golden['refine_nobn_rot'], 0.15, 'no-BN 6d rot head')
   np.testing.assert_allclose(trans.numpy(), golden['refine_nobn_trans'], atol=2e-3)
   np.testing.assert_allclose(rot.numpy(), golden['refine_nobn_rot'], atol=2e-3)
 
 
 def test_score_net_vs_reference_golden(nets_gpu, golden):
   from foundationpose_amd._lib import check, lib, ptr, stream_ptr
-  A, B = net_inputs(13, 4)
+  A, B = net_inputs(13, 8)
+  feat = _tokens_gpu(nets_gpu, nets_gpu['snet'], A, B)
+  assert_tracks_input(feat[:, ::64, ::4, ::4].numpy(), golden['score_encAB4_sub'], 0.1, 'encoderAB[4] tap')
   x = to_net_tensor(A, B)
-  feats = torch.empty((4, 512), device='cuda')
-  check(lib().fp_score_features(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(x), 4, ptr(feats), stream_ptr()))
-  scale = float(np.abs(golden['score_feats']).max())
-  np.testing.assert_allclose(feats.cpu().numpy(), golden['score_feats'], atol=3e-3 * scale)
-  for L, key in ((4, 'score_logit_L4'), (2, 'score_logit_L2')):
-    logits = torch.empty((4 // L, L), device='cuda')
-    am = torch.empty((4 // L,), dtype=torch.int32, device='cuda')
-    check(lib().fp_score_tail(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(feats), 4 // L, L, ptr(logits), ptr(am), stream_ptr()))
-    np.testing.assert_allclose(logits.cpu().numpy(), golden[key], atol=2e-3)
+  feats = torch.empty((8, 512), device='cuda')
+  check(lib().fp_score_features(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(x), 8, ptr(feats), stream_ptr()))
+  assert_tracks_input(feats.cpu().numpy(), golden['score_feats'], 0.1, 'ScoreNet features')
+  for L, key in ((8, 'score_logit_L8'), (4, 'score_logit_L4')):
+    logits = torch.empty((8 // L, L), device='cuda')
+    am = torch.empty((8 // L,), dtype=torch.int32, device='cuda')
+    check(lib().fp_score_tail(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(feats), 8 // L, L, ptr(logits), ptr(am), stream_ptr()))
+    want = golden[key]
+    got = logits.cpu().numpy()
+    spread = float(want.std())
+    err = float(np.abs((got - got.mean(-1, keepdims=True)) - (want - want.mean(-1, keepdims=True))).max())
+    print(f'{key}: logit spread {spread:.2e}, differential error {err:.2e}')
+    assert err < 0.1 * spread
+    np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
     # the tail itself (fp32 SIMT) on the REFERENCE features must reproduce the reference logits tightly
     fref = torch.from_numpy(golden['score_feats']).cuda()
-    check(lib().fp_score_tail(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(fref), 4 // L, L, ptr(logits), ptr(am), stream_ptr()))
-    np.testing.assert_allclose(logits.cpu().numpy(), golden[key], atol=2e-5)
-    np.testing.assert_array_equal(am.cpu().numpy(), golden[key].argmax(-1))
+    check(lib().fp_score_tail(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(fref), 8 // L, L, ptr(logits), ptr(am), stream_ptr()))
+    np.testing.assert_allclose(logits.cpu().numpy(), want, atol=2e-5)
+    np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
 
 
 def test_state_dict_errors(nets_gpu):
@@ -119,7 +166,7 @@ def test_register_matches_oracle_config0(estimators):
   """BASELINE config[0] (32 hypotheses, est_refine_iter=1) and a 2-iteration run.
   Per hypothesis: refined 4x4 pose within 1e-3 of the oracle (north_star tolerance); score logits
   within the fp16 noise floor (<5 % of the logit spread across hypotheses); identical argmax and
-  best pose whenever the oracle's top-1/top-2 margin exceeds 4x the measured logit noise."""
+  best pose, with the oracle's top-1/top-2 margin at least 20x the measured logit noise."""
   from oracle import geometry as G
   from oracle import predict as OP
   sc, est, orc = estimators['sc'], estimators['est'], estimators['orc']
@@ -150,16 +197,19 @@ def test_register_matches_oracle_config0(estimators):
       print(f'iteration={iteration}: logit common shift {common:.2e}, differential noise {noise:.2e}, spread {spread:.2e}, '
             f'top1-top2 margin {margin:.2e}, argmax gpu/oracle {int(sg.argmax())}/{int(so.argmax())}')
       assert abs(common) < 5e-3 and noise < 0.25 * spread
-      if margin > 4 * noise:
-        assert int(sg.argmax()) == int(so.argmax())
+      # identical argmax, unconditionally: the ScoreNet tail seed is chosen (tests/golden/gen_fullsize.py) so that the oracle's
+      # top-1 / top-2 margin is far above the fp16 logit noise in every case of tests/cases.py
+      assert margin >= 20 * noise, f'margin {margin:.2e} vs logit noise {noise:.2e}'
+      assert int(sg.argmax()) == int(so.argmax())
       # the integrated call
       pose_g = est.register(K=sc['K'], rgb=sc['rgb'], depth=sc['depth'], ob_mask=sc['mask'], iteration=iteration)
       pose_o = orc.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=iteration, chunk=16)
       assert pose_g.dtype == np.float32 and pose_g.shape == (4, 4)
       assert est.poses.shape == (32, 4, 4) and est.scores.shape == (32,)
       assert bool((est.scores[:-1] >= est.scores[1:]).all())
-      if margin > 4 * noise and int(est.best_id) == int(orc.best_id):
-        np.testing.assert_allclose(pose_g, pose_o, atol=1e-3)
+      assert int(est.best_id) == int(orc.best_id)
+      np.testing.assert_allclose(pose_g, pose_o, atol=1e-3)
+      np.testing.assert_allclose(est.poses.cpu().numpy(), np.asarray(orc.poses), atol=1e-3)      # all 32, in score order
   finally:
     est.rot_grid, orc.rot_grid = full_g, full_o
 
@@ -345,7 +395,8 @@ def test_register_textured_symmetric_object():
   pose_o = orc.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=1, chunk=12)
   so, sg = np.asarray(orc.scores), est.scores.cpu().numpy()           # both sorted, best first
   np.testing.assert_allclose(sg, so, atol=3e-3)
-  if so[0] - so[1] > 2e-3:                                             # top-1 / top-2 margin above the fp16 logit noise
-    assert int(est.best_id) == int(orc.best_id)
-    np.testing.assert_allclose(pose_g, pose_o, atol=1e-3)
-    np.testing.assert_allclose(est.poses[0].cpu().numpy(), np.asarray(orc.poses[0]), atol=1e-3)
+  noise = float(np.abs((sg - sg.mean()) - (so - so.mean())).max())
+  assert so[0] - so[1] >= 20 * noise, f'margin {so[0] - so[1]:.2e} vs logit noise {noise:.2e}'      # case tex24 of tests/cases.py
+  assert int(est.best_id) == int(orc.best_id)
+  np.testing.assert_allclose(pose_g, pose_o, atol=1e-3)
+  np.testing.assert_allclose(est.poses.cpu().numpy(), np.asarray(orc.poses), atol=1e-3)

@@ -1,5 +1,6 @@
 """CPU: the host-side helpers of the product package against vectors produced by the
-reference's own functions (tests/golden/gen_golden.py).  No kernel is called; the numpy / torch-CPU branches run."""
+reference's own functions (tests/golden/gen_golden.py).  No kernel is called; the numpy / torch-CPU branches run
+(depth2xyzmap runs the device kernel for numpy input too: its golden check is tests/test_gpu_kernels.py)."""
 import types
 
 import numpy as np
@@ -14,10 +15,6 @@ def test_projection_and_camera_convention(golden):
     P = U.projection_matrix_from_intrinsics(S.YCB_K, height=480, width=640, znear=0.001, zfar=100, window_coords=mode)
     np.testing.assert_allclose(P, golden[key], rtol=0, atol=1e-15)
   np.testing.assert_array_equal(U.glcam_in_cvcam, golden['glcam_in_cvcam'])
-
-
-def test_depth2xyzmap_numpy_branch(golden):
-  np.testing.assert_array_equal(U.depth2xyzmap(golden['d2x_depth'], S.YCB_K), golden['d2x_xyz'])
 
 
 def test_pose_algebra(golden):

@@ -6,22 +6,12 @@ import torch
 from foundationpose_amd import synthetic as S
 from oracle import geometry as G
 from oracle import nets
-
-
-def net_inputs(seed, n):
-  rs = np.random.RandomState(seed)
-  out = []
-  for _ in range(2):
-    rgb = rs.uniform(0, 1, (n, 3, 160, 160)).astype(np.float32)
-    xyz = (rs.randn(n, 3, 160, 160) * 0.5).astype(np.float32)
-    xyz[np.broadcast_to(rs.uniform(size=(n, 1, 160, 160)) < 0.4, xyz.shape)] = 0
-    out.append(torch.from_numpy(np.concatenate([rgb, xyz], 1)))
-  return out
+from tests.util import net_inputs
 
 
 def test_refine_net_matches_reference_module(golden):
   sd = S.make_refine_state_dict(seed=0)
-  A, B = net_inputs(11, 2)
+  A, B = net_inputs(11, 8)
   taps = {}
   o = nets.refine_forward(sd, A, B, use_bn=True, taps=taps)
   # fp32 CPU, different op grouping (functional vs nn.Module): 1e-5 absolute on O(0.1) outputs
@@ -29,11 +19,13 @@ def test_refine_net_matches_reference_module(golden):
   np.testing.assert_allclose(o['rot'].numpy(), golden['refine_rot'], atol=2e-5, rtol=1e-4)
   np.testing.assert_allclose(taps['encA3'][:, ::16, ::8, ::8].numpy(), golden['refine_encA3_sub'], atol=1e-4, rtol=1e-4)
   np.testing.assert_allclose(taps['encAB4'][:, ::64, ::4, ::4].numpy(), golden['refine_encAB4_sub'], atol=1e-4, rtol=1e-4)
+  # the vectors are able to fail: the reference's outputs differ from sample to sample by far more than the tolerance
+  assert golden['refine_trans'].std(0).min() > 100 * 2e-5 and golden['refine_rot'].std(0).min() > 100 * 2e-5
 
 
 def test_refine_net_no_bn_6d(golden):
   sd = S.make_refine_state_dict(seed=2, use_bn=False, rot_out_dim=6)
-  A, B = net_inputs(12, 1)
+  A, B = net_inputs(12, 4)
   o = nets.refine_forward(sd, A, B, use_bn=False)
   np.testing.assert_allclose(o['trans'].numpy(), golden['refine_nobn_trans'], atol=2e-5, rtol=1e-4)
   np.testing.assert_allclose(o['rot'].numpy(), golden['refine_nobn_rot'], atol=2e-5, rtol=1e-4)
@@ -41,12 +33,13 @@ def test_refine_net_no_bn_6d(golden):
 
 def test_score_net_matches_reference_module(golden):
   sd = S.make_score_state_dict(seed=1)
-  A, B = net_inputs(13, 4)
+  A, B = net_inputs(13, 8)
   feats = nets.score_extract_feat(sd, A, B, use_bn=True)
   np.testing.assert_allclose(feats.numpy(), golden['score_feats'], atol=1e-4, rtol=1e-4)
+  np.testing.assert_allclose(nets.score_tail(sd, feats, 8).numpy(), golden['score_logit_L8'], atol=1e-4, rtol=1e-4)
   np.testing.assert_allclose(nets.score_tail(sd, feats, 4).numpy(), golden['score_logit_L4'], atol=1e-4, rtol=1e-4)
-  np.testing.assert_allclose(nets.score_tail(sd, feats, 2).numpy(), golden['score_logit_L2'], atol=1e-4, rtol=1e-4)
-  assert int(nets.score_tail(sd, feats, 4).argmax()) == int(golden['score_logit_L4'].argmax())
+  assert int(nets.score_tail(sd, feats, 8).argmax()) == int(golden['score_logit_L8'].argmax())
+  assert (nets.score_tail(sd, feats, 4).argmax(-1).numpy() == golden['score_logit_L4'].argmax(-1)).all()
 
 
 def test_positional_embedding(golden):

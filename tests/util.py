@@ -50,3 +50,27 @@ def mismatch_report(a, b, atol):
   d = np.abs(a - b)
   bad = d > atol
   return float(bad.mean()), float(d.max()), float(np.median(d))
+
+
+def net_inputs(seed, n):
+  """(A, B) network inputs (n,6,160,160) float32 that DIFFER from sample to sample the way rendered / observed crops do:
+  smooth colour and coordinate fields of seeded frequency and amplitude inside a seeded elliptic silhouette, exact zeros
+  outside (masked background), a little pixel noise.  The across-sample spread of the network outputs is what the golden
+  tests measure their tolerance against (a kernel that ignored or permuted its input must fail them)."""
+  rs = np.random.RandomState(seed)
+  vs, us = np.meshgrid(np.arange(160.0), np.arange(160.0), indexing='ij')
+  sides = []
+  for _ in range(2):
+    imgs = np.zeros((n, 6, 160, 160), dtype=np.float32)
+    for i in range(n):
+      f, ph = rs.uniform(0.02, 0.3, (6, 2)), rs.uniform(0, 2 * np.pi, 6)
+      base = np.stack([np.sin(us * f[c, 0] + vs * f[c, 1] + ph[c]) for c in range(6)])
+      rgb = np.clip(0.5 + 0.45 * rs.uniform(0.3, 1.0) * base[:3] + rs.randn(3, 160, 160) * 0.04, 0, 1)
+      xyz = rs.uniform(0.2, 1.2) * base[3:] + rs.randn(3, 160, 160) * 0.04
+      cx, cy, rx, ry = rs.uniform(60, 100), rs.uniform(60, 100), rs.uniform(25, 75), rs.uniform(25, 75)
+      inside = ((us - cx) / rx) ** 2 + ((vs - cy) / ry) ** 2 < 1
+      xyz[:, ~inside] = 0
+      rgb[:, ~inside] *= rs.uniform(0.0, 1.0)          # dimmed or black background
+      imgs[i, :3], imgs[i, 3:] = rgb, xyz
+    sides.append(torch.from_numpy(imgs))
+  return sides
