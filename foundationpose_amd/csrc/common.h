@@ -206,6 +206,29 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 // accumulator registers of a k-step) are then 16 contiguous bytes - one ds_read_b128 per V^T fragment.
 __host__ __device__ __forceinline__ int vt_col(int t) { return (t & ~15) | (((t >> 2) & 1) << 3) | (((t >> 3) & 1) << 2) | (t & 3); }
 int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s);
+
+// Token GEMM (tok_gemm.hip): out = x (M x 512) @ W^T + b for up to TG_MAXBLK blocks of 512 output columns in one launch.
+#define TG_MAXBLK 6
+struct TokGemmBlock {
+  const f16 *w;        // 512 x 512 weights in MFMA-fragment order (pack_tok_weights)
+  const float *bias;   // 512
+  void *out;           // fp16 rows (EPI_ROWS / EPI_LN) or the transposed V image (EPI_VT)
+  int ld, coff;        // row stride / column offset of this block in `out` (halfs)
+  int relu;
+};
+struct TokGemmArgs {
+  const f16 *in;       // [M][512] fp16
+  int M, nblk, tokens; // tokens per hypothesis (EPI_VT, EPI_LNSUM)
+  TokGemmBlock blk[TG_MAXBLK];
+  const f16 *res;      // [M][512] residual (EPI_LN, EPI_LNSUM)
+  const float *gamma, *beta;
+  float *gsum;         // EPI_LNSUM: [M/16][512] sums of the normalised rows over groups of 16 tokens
+};
+enum { TG_EPI_ROWS = 0, TG_EPI_VT = 1, TG_EPI_LN = 2, TG_EPI_LNSUM = 3 };
+int launch_tok_gemm(fp_ctx *ctx, const TokGemmArgs &a, int epi, hipStream_t s);
+// Sum of `nparts` consecutive partial rows per hypothesis (fixed order) / T, gamma, beta, Linear(512 -> out_dim)
+int launch_mean_head(const float *partial, int nparts, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
+                     int out_dim, float *out, hipStream_t s);
 int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s);
 int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
 int launch_layernorm_h(const f16 *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);

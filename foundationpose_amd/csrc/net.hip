@@ -14,8 +14,13 @@ struct ConvW {
   int Cin = 0, Cout = 0, K = 1, Kpad = 0, stride = 1;
 };
 
+struct LinP {   // 512 rows of an nn.Linear(512, .) in the fragment order tok_gemm.hip reads (pack_tok_weights)
+  f16 *w = nullptr;
+  float *bias = nullptr;
+};
+
 struct HeadW {  // one nn.TransformerEncoderLayer + Linear
-  ConvW qk, v, out, ff1, ff2;
+  LinP q, k, v, out, ff1, ff2;
   float *ln1g = nullptr, *ln1b = nullptr, *ln2g = nullptr, *ln2b = nullptr, *hw = nullptr, *hb = nullptr;
   int out_dim = 0;
 };
@@ -30,7 +35,7 @@ struct fp_net {
   ConvW trunk[15];
   float *pe = nullptr;  // 400 x 512
   HeadW heads[2];       // refine: trans, rot
-  ConvW att_qk, att_v;  // score: self.att in_proj on tokens
+  LinP att_q, att_k, att_v;  // score: self.att in_proj on tokens
   LinF32 att_out, cross_in, cross_out, lin;
   std::vector<void *> allocs;
 };
@@ -126,24 +131,31 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
   return FP_OK;
 }
 
-// rows [r0, r1) of a (R, K) linear weight as a 1x1 "conv"
-int make_linear(fp_net *net, const SD &sd, const std::string &wkey, const std::string &bkey, int r0, int r1, int K, ConvW *out) {
+// 512 x 512 row-major fp32 -> fp16 in the fragment order of tok_gemm.hip
+void pack_tok_weights(const float *w, f16 *out) {
+  for (int wave = 0; wave < 8; ++wave)
+    for (int k16 = 0; k16 < 32; ++k16)
+      for (int i = 0; i < 2; ++i)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int lr = lane & 31, lh = lane >> 5;
+          const float *src = w + (size_t)(wave * 64 + i * 32 + lr) * 512 + k16 * 16 + lh * 8;
+          f16 *dst = out + ((((size_t)wave * 32 + k16) * 2 + i) * 64 + lane) * 8;
+          for (int e = 0; e < 8; ++e) dst[e] = (f16)src[e];
+        }
+}
+
+// rows [r0, r0 + 512) of an (R, 512) linear weight in the MFMA-fragment order of tok_gemm.hip: [wave 8][k16 32][i 2][lane 64][8],
+// lane (lh*32 + lr) of fragment (wave, k16, i) holds W[r0 + wave*64 + i*32 + lr][k16*16 + lh*8 .. + 8] - one coalesced
+// 1-KB load per fragment
+int make_linear(fp_net *net, const SD &sd, const std::string &wkey, const std::string &bkey, int r0, LinP *out) {
   const fp_tensor *w, *b;
-  FP_TRY(need(sd, wkey, 2, {-1, K}, &w));
+  FP_TRY(need(sd, wkey, 2, {-1, 512}, &w));
   FP_TRY(need(sd, bkey, 1, {w->shape[0]}, &b));
-  FP_REQUIRE(r1 <= w->shape[0], "linear '%s': rows out of range", wkey.c_str());
-  const int N = r1 - r0;
-  std::vector<f16> hw((size_t)N * K);
-  std::vector<float> hb(N);
-  for (int n = 0; n < N; ++n) {
-    for (int k = 0; k < K; ++k) hw[(size_t)n * K + k] = (f16)w->data[(size_t)(r0 + n) * K + k];
-    hb[n] = b->data[r0 + n];
-  }
-  out->Cin = K;
-  out->Cout = N;
-  out->K = 1;
-  out->Kpad = K;
-  out->stride = 1;
+  FP_REQUIRE(r0 + 512 <= w->shape[0], "linear '%s': rows out of range", wkey.c_str());
+  std::vector<f16> hw((size_t)512 * 512);
+  std::vector<float> hb(512);
+  pack_tok_weights(w->data + (size_t)r0 * 512, hw.data());
+  for (int n = 0; n < 512; ++n) hb[n] = b->data[r0 + n];
   FP_TRY(upload(net, hw, &out->w));
   FP_TRY(upload(net, hb, &out->bias));
   return FP_OK;
@@ -211,11 +223,12 @@ extern "C" int fp_net_create(fp_ctx *ctx, int kind, const fp_tensor *tensors, in
       for (int h = 0; h < 2; ++h) {
         HeadW &H = net->heads[h];
         std::string p = std::string(names[h]) + ".0";
-        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 0, 1024, 512, &H.qk));
-        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 1024, 1536, 512, &H.v));
-        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", 0, 512, 512, &H.out));
-        FP_TRY(make_linear(net.get(), sd, p + ".linear1.weight", p + ".linear1.bias", 0, 512, 512, &H.ff1));
-        FP_TRY(make_linear(net.get(), sd, p + ".linear2.weight", p + ".linear2.bias", 0, 512, 512, &H.ff2));
+        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 0, &H.q));
+        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 512, &H.k));
+        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", 1024, &H.v));
+        FP_TRY(make_linear(net.get(), sd, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", 0, &H.out));
+        FP_TRY(make_linear(net.get(), sd, p + ".linear1.weight", p + ".linear1.bias", 0, &H.ff1));
+        FP_TRY(make_linear(net.get(), sd, p + ".linear2.weight", p + ".linear2.bias", 0, &H.ff2));
         FP_TRY(make_vec(net.get(), sd, p + ".norm1.weight", 512, &H.ln1g));
         FP_TRY(make_vec(net.get(), sd, p + ".norm1.bias", 512, &H.ln1b));
         FP_TRY(make_vec(net.get(), sd, p + ".norm2.weight", 512, &H.ln2g));
@@ -229,8 +242,9 @@ extern "C" int fp_net_create(fp_ctx *ctx, int kind, const fp_tensor *tensors, in
       }
     } else {
       FP_TRY(make_trunk(net.get(), sd, "encoderA", "encoderAB", use_bn));
-      FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 0, 1024, 512, &net->att_qk));
-      FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 1024, 1536, 512, &net->att_v));
+      FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 0, &net->att_q));
+      FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 512, &net->att_k));
+      FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 1024, &net->att_v));
       FP_TRY(make_linf32(net.get(), sd, "att.out_proj.weight", "att.out_proj.bias", 512, 512, &net->att_out));
       FP_TRY(make_linf32(net.get(), sd, "att_cross.in_proj_weight", "att_cross.in_proj_bias", 1536, 512, &net->cross_in));
       FP_TRY(make_linf32(net.get(), sd, "att_cross.out_proj.weight", "att_cross.out_proj.bias", 512, 512, &net->cross_out));
@@ -356,14 +370,27 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
   return FP_OK;
 }
 
-// q|k and transposed-v projections + fused attention: tokens (M,512) -> att (M,512)
-int run_mha_core(fp_ctx *ctx, const ConvW &qkw, const ConvW &vw, const f16 *tok, int N, f16 *qk, f16 *vt, f16 *att, hipStream_t s) {
-  const int M = N * 400;
-  Conv2dCall c;
-  c = Conv2dCall{tok, M, 1, 1, &qkw}; c.relu = 0; c.out = qk; FP_TRY(run_conv(ctx, c, s));
-  FP_TRY(launch_vt_pad_zero(vt, N, 400, s));
-  c = Conv2dCall{tok, M, 1, 1, &vw}; c.relu = 0; c.out = vt; c.out_mode = 2; c.tokens = 400; FP_TRY(run_conv(ctx, c, s));
-  return launch_attention(ctx, qk, vt, N, 400, att, s);
+// q|k and transposed-V in-projections of up to two attention layers that read the SAME tokens (RefineNet's two heads;
+// one for ScoreNet): one launch for every q / k block (fp16 rows [M][1024] = q | k per layer), one for the V^T images
+int run_qkv(fp_ctx *ctx, const LinP *const *q, const LinP *const *k, const LinP *const *v, int n_layers, const f16 *tok, int N, f16 *const *qk,
+            f16 *const *vt, hipStream_t s) {
+  TokGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = tok;
+  a.M = N * 400;
+  a.tokens = 400;
+  a.nblk = 2 * n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    a.blk[2 * l] = TokGemmBlock{q[l]->w, q[l]->bias, qk[l], 1024, 0, 0};
+    a.blk[2 * l + 1] = TokGemmBlock{k[l]->w, k[l]->bias, qk[l], 1024, 512, 0};
+  }
+  FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_ROWS, s));
+  a.nblk = n_layers;
+  for (int l = 0; l < n_layers; ++l) {
+    FP_TRY(launch_vt_pad_zero(vt[l], N, 400, s));
+    a.blk[l] = TokGemmBlock{v[l]->w, v[l]->bias, vt[l], 0, 0, 0};
+  }
+  return launch_tok_gemm(ctx, a, TG_EPI_VT, s);
 }
 
 }  // namespace
@@ -389,30 +416,50 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     // buffers and its own stream, so the tail of one head's kernels overlaps the other's (their launches are 3.08 rounds of
     // workgroups each)
     float *outs[2] = {d_trans + (size_t)s0 * 3, d_rot + (size_t)s0 * net->heads[1].out_dim};
-    f16 *qk[2], *vt[2], *att[2], *y16[2], *x1[2], *ff[2];
-    float *lnpart[2];
+    f16 *qk[2], *vt[2], *att[2], *x1[2], *ff[2];
+    float *gsum[2];
     for (int h = 0; h < 2; ++h) {
       TAKE(qk_, f16, (size_t)M * 1024);
       TAKE(vt_, f16, (size_t)N * 4 * 128 * 416);
       TAKE(att_, f16, (size_t)M * 512);
-      TAKE(y16_, f16, (size_t)M * 512);   // pre-LayerNorm sums, fp16 like the reference's autocast path
       TAKE(x1_, f16, (size_t)M * 512);
       TAKE(ff_, f16, (size_t)M * 512);
-      TAKE(lnpart_, float, (size_t)N * 8 * 512);
-      qk[h] = qk_, vt[h] = vt_, att[h] = att_, y16[h] = y16_, x1[h] = x1_, ff[h] = ff_, lnpart[h] = lnpart_;
+      TAKE(gsum_, float, (size_t)(M / 16) * 512);
+      qk[h] = qk_, vt[h] = vt_, att[h] = att_, x1[h] = x1_, ff[h] = ff_, gsum[h] = gsum_;
     }
+    // in-projections of BOTH heads: the tokens are staged once per workgroup for 512 output columns of either head
+    const LinP *q_[2] = {&net->heads[0].q, &net->heads[1].q}, *k_[2] = {&net->heads[0].k, &net->heads[1].k}, *v_[2] = {&net->heads[0].v, &net->heads[1].v};
+    FP_TRY(run_qkv(ctx, q_, k_, v_, 2, tok, N, qk, vt, s));
     static const bool serial_heads = getenv("FP_HEADS_SERIAL") != nullptr;      // A/B timing knob
     StreamFanout fo(ctx, s, serial_heads ? 1 : 2);
     for (int h = 0; h < 2; ++h) {
       const HeadW &H = net->heads[h];
       hipStream_t sh = h == 0 ? s : fo.stream_for(0);
-      FP_TRY(run_mha_core(ctx, H.qk, H.v, tok, N, qk[h], vt[h], att[h], sh));
-      Conv2dCall c;
-      c = Conv2dCall{att[h], M, 1, 1, &H.out}; c.relu = 0; c.res = tok; c.out = y16[h]; FP_TRY(run_conv(ctx, c, sh));
-      FP_TRY(launch_layernorm_h(y16[h], H.ln1g, H.ln1b, M, x1[h], sh));
-      c = Conv2dCall{x1[h], M, 1, 1, &H.ff1}; c.relu = 1; c.out = ff[h]; FP_TRY(run_conv(ctx, c, sh));
-      c = Conv2dCall{ff[h], M, 1, 1, &H.ff2}; c.relu = 0; c.res = x1[h]; c.out = y16[h]; FP_TRY(run_conv(ctx, c, sh));
-      FP_TRY(launch_ln_mean_head_h(y16[h], H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], lnpart[h], sh));
+      FP_TRY(launch_attention(ctx, qk[h], vt[h], N, 400, att[h], sh));
+      TokGemmArgs a;
+      memset(&a, 0, sizeof(a));
+      a.M = M;
+      a.tokens = 400;
+      a.nblk = 1;
+      // x1 = norm1(tok + out_proj(att))
+      a.in = att[h];
+      a.blk[0] = TokGemmBlock{H.out.w, H.out.bias, x1[h], 512, 0, 0};
+      a.res = tok;
+      a.gamma = H.ln1g;
+      a.beta = H.ln1b;
+      FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_LN, sh));
+      // ff = relu(linear1(x1))
+      a.in = x1[h];
+      a.blk[0] = TokGemmBlock{H.ff1.w, H.ff1.bias, ff[h], 512, 0, 1};
+      a.res = nullptr;
+      FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_ROWS, sh));
+      // norm2(x1 + linear2(ff)) summed over groups of 16 tokens, then mean over the 400 tokens + Linear(512, out_dim)
+      a.in = ff[h];
+      a.blk[0] = TokGemmBlock{H.ff2.w, H.ff2.bias, nullptr, 512, 0, 0};
+      a.res = x1[h];
+      a.gsum = gsum[h];
+      FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_LNSUM, sh));
+      FP_TRY(launch_mean_head(gsum[h], 25, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], sh));
     }
     FP_TRY(fo.join());
     return FP_OK;
@@ -424,6 +471,44 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     rc = body(s0, std::min(CH, NT - s0));
     ctx->arena.off = mark;
   }
+  return rc;
+}
+
+// Building block for the parity tests: one 512 -> 512 token Linear with one of the fused epilogues of tok_gemm.hip.
+extern "C" int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const float *h_weight, const float *h_bias, int epilogue, int relu,
+                                   const void *d_res, const float *h_gamma, const float *h_beta, int tokens, void *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_in && h_weight && h_bias && d_out, "fp_token_linear_f16: null argument");
+  FP_REQUIRE(epilogue >= TG_EPI_ROWS && epilogue <= TG_EPI_LNSUM, "fp_token_linear_f16: epilogue %d unknown", epilogue);
+  FP_CHECK_HIP(hipSetDevice(ctx->device));
+  std::vector<f16> hw((size_t)512 * 512);
+  pack_tok_weights(h_weight, hw.data());
+  char *dev = nullptr;
+  FP_CHECK_HIP(hipMalloc((void **)&dev, hw.size() * 2 + 3 * 512 * 4));
+  float *d_bias = (float *)(dev + hw.size() * 2), *d_g = d_bias + 512, *d_b = d_g + 512;
+  int rc = FP_OK;
+  auto run = [&]() -> int {
+    FP_CHECK_HIP(hipMemcpy(dev, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    FP_CHECK_HIP(hipMemcpy(d_bias, h_bias, 512 * 4, hipMemcpyHostToDevice));
+    if (h_gamma) FP_CHECK_HIP(hipMemcpy(d_g, h_gamma, 512 * 4, hipMemcpyHostToDevice));
+    if (h_beta) FP_CHECK_HIP(hipMemcpy(d_b, h_beta, 512 * 4, hipMemcpyHostToDevice));
+    TokGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = (const f16 *)d_in;
+    a.M = M;
+    a.nblk = 1;
+    a.tokens = tokens;
+    a.blk[0] = TokGemmBlock{(const f16 *)dev, d_bias, d_out, 512, 0, relu};
+    a.res = (const f16 *)d_res;
+    a.gamma = h_gamma ? d_g : nullptr;
+    a.beta = h_beta ? d_b : nullptr;
+    a.gsum = (float *)d_out;
+    if (epilogue == TG_EPI_VT) FP_TRY(launch_vt_pad_zero((f16 *)d_out, tokens > 0 ? M / tokens : 0, tokens, (hipStream_t)stream));
+    FP_TRY(launch_tok_gemm(ctx, a, epilogue, (hipStream_t)stream));
+    FP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return FP_OK;
+  };
+  rc = run();
+  (void)hipFree(dev);
   return rc;
 }
 
@@ -465,7 +550,10 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
     TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
     TAKE(att, f16, (size_t)M * 512);
     TAKE(mean, float, (size_t)N * 512);
-    FP_TRY(run_mha_core(ctx, net->att_qk, net->att_v, tok, N, qk, vt, att, s));
+    const LinP *q_[1] = {&net->att_q}, *k_[1] = {&net->att_k}, *v_[1] = {&net->att_v};
+    f16 *qk_[1] = {qk}, *vt_[1] = {vt};
+    FP_TRY(run_qkv(ctx, q_, k_, v_, 1, tok, N, qk_, vt_, s));
+    FP_TRY(launch_attention(ctx, qk, vt, N, 400, att, s));
     // mean over tokens commutes with out_proj (score_network.py:73-74)
     FP_TRY(launch_token_mean(att, N, 400, mean, s));
     FP_TRY(launch_small_linear(mean, net->att_out.w, net->att_out.b, N, 512, 512, d_feats + (size_t)s0 * 512, s));

@@ -199,7 +199,7 @@ class FoundationPose:
     self.pose_last = pose
     return (pose @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)
 
-  def track_multi(self, rgb, depth, K, iteration, n_hypotheses=64, trans_sigma=0.003, rot_sigma_deg=1.5, extra={}):
+  def track_multi(self, rgb, depth, K, iteration, n_hypotheses=64, trans_sigma=0.01, rot_sigma_deg=5.0, extra={}):
     """Multi-hypothesis tracking (BASELINE.json configs[4]; a build extension, the reference's track_one refines one pose
     and never scores): the previous pose and n-1 fixed seeded perturbations of it (tracking.tracking_hypotheses) are refined
     together, scored by ScoreNet, and the best-scoring refined pose becomes `pose_last`.  Same prelude and return value as

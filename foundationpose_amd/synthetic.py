@@ -191,9 +191,11 @@ def _linear(rs, sd, name, cout, cin, gain=1.0):
   sd[f'{name}.bias'] = torch.from_numpy(rs.uniform(-bound, bound, cout).astype(np.float32))
 
 
-def _mha(rs, sd, name, d=512, qk_gain=1.0):
+def _mha(rs, sd, name, d=512, qk_gain=1.0, tie_qk=False):
   bound = math.sqrt(6.0 / (d + 3 * d))
   w = rs.uniform(-bound, bound, (3 * d, d)).astype(np.float32)
+  if tie_qk:
+    w[d:2 * d] = w[:d]          # Wk = Wq: a hypothesis' query is most similar to keys of hypotheses like itself
   w[:2 * d] *= qk_gain
   sd[f'{name}.in_proj_weight'] = torch.from_numpy(w)
   sd[f'{name}.in_proj_bias'] = torch.from_numpy((rs.randn(3 * d) * 0.02).astype(np.float32))
@@ -267,7 +269,7 @@ def make_refine_state_dict(seed=0, c_in=6, use_bn=True, rot_out_dim=3, head_gain
 
 
 # ScoreNet tail seeds chosen by tests/golden/gen_fullsize.py (stage 'tail'): largest worst-case top-1 / top-2 margin
-_TAIL_SEED = {1: 2640}
+_TAIL_SEED = {1: 521}
 
 
 def make_score_state_dict(seed=1, c_in=6, use_bn=True, tail_seed=None, tail_only=False):
@@ -281,8 +283,11 @@ def make_score_state_dict(seed=1, c_in=6, use_bn=True, tail_seed=None, tail_only
     _mha(rs, sd, 'att')
     sd['pos_embed.pe'] = positional_embedding()
   rt = np.random.RandomState(_TAIL_SEED.get(seed, seed + 1000) if tail_seed is None else tail_seed)
-  # with xavier-sized q/k the cross-hypothesis softmax is uniform and every hypothesis gets the same logit;
-  # a larger q/k gain makes the seeded scorer discriminate between hypotheses (hard parts)
-  _mha(rt, sd, 'att_cross', qk_gain=30.0)
+  # with xavier-sized q/k the cross-hypothesis softmax is uniform and every hypothesis gets the same logit (the logit is
+  # a softmax-weighted mean over ALL hypotheses of a per-hypothesis scalar); a larger q/k gain with tied projections makes a
+  # hypothesis attend to those that resemble it, so the seeded scorer discriminates.  Gain 7 keeps the softmax soft enough
+  # that the fp16 error common to all hypotheses (weight rounding) does not tip it: measured worst-case margin / logit
+  # noise over the cases of tests/cases.py 63 at gain 7, 38 at 10, 17 at 15, 1 at 30 (hard parts)
+  _mha(rt, sd, 'att_cross', qk_gain=7.0, tie_qk=True)
   _linear(rt, sd, 'linear', 1, 512)
   return sd

@@ -12,7 +12,7 @@ import torch
 
 
 @functools.lru_cache(maxsize=8)
-def perturbation_set(n, trans_sigma=0.003, rot_sigma_deg=1.5, seed=0):
+def perturbation_set(n, trans_sigma=0.01, rot_sigma_deg=5.0, seed=0):
   """(n,4,4) float32: identity first, then n-1 small rigid motions [dR | dt] with dt ~ N(0, trans_sigma) per axis and
   dR = exp(hat(w)), w ~ N(0, rot_sigma) per axis."""
   rs = np.random.RandomState(seed)
@@ -27,7 +27,7 @@ def perturbation_set(n, trans_sigma=0.003, rot_sigma_deg=1.5, seed=0):
   return out.astype(np.float32)
 
 
-def tracking_hypotheses(pose, n, trans_sigma=0.003, rot_sigma_deg=1.5, seed=0):
+def tracking_hypotheses(pose, n, trans_sigma=0.01, rot_sigma_deg=5.0, seed=0):
   """pose (4,4) tensor -> (n,4,4) hypotheses on its device: R_i = dR_i R, t_i = t + dt_i (the egocentric update form of
   the refiner, src/Utils.py:848-855); hypothesis 0 is `pose` itself."""
   P = torch.as_tensor(perturbation_set(int(n), float(trans_sigma), float(rot_sigma_deg), int(seed)), device=pose.device)

@@ -179,6 +179,16 @@ int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin
  * (tokens of a group of 16 in the order 0-3, 8-11, 4-7, 12-15); columns of tokens >= T must hold zeros. */
 int fp_attention_f16(fp_ctx *ctx, const void *d_qk, const void *d_vt, int B, int T, void *d_out, void *stream);
 
+/* One nn.Linear(512, 512) on M tokens with the epilogue the transformer heads fuse behind it (csrc/tok_gemm.hip;
+ * nn.TransformerEncoderLayer / nn.MultiheadAttention, refine_network.py:56-70, score_network.py:53-54):
+ *   epilogue 0: out = [relu](x W^T + b), fp16 [M][512]
+ *            1: the same values as the transposed V image [M/tokens][4][128][416] (layout: fp_attention_f16)
+ *            2: out = LayerNorm(res + x W^T + b) * gamma + beta, fp16 [M][512] (statistics and residual in fp32)
+ *            3: sums over groups of 16 tokens of the normalised rows (before gamma / beta), fp32 [M/16][512]
+ * h_weight (512x512 row-major) / h_bias / h_gamma / h_beta are host fp32; synchronises the stream. */
+int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const float *h_weight, const float *h_bias, int epilogue, int relu,
+                        const void *d_res, const float *h_gamma, const float *h_beta, int tokens, void *d_out, void *stream);
+
 /* mycpp.cluster_poses (mycpp/src/app/pybind_api.cpp:24-68); host function, float32 row-major 4x4.
  * h_out must hold n_in*16 floats; returns the number of kept poses (>=1) or a negative error. */
 int fp_cluster_poses(float angle_diff_deg, float dist_diff_m, const float *h_poses_in, int n_in, const float *h_symmetry_tfs,

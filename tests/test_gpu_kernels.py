@@ -322,6 +322,59 @@ def test_conv_rejects_bad_shapes(fp):
     check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(x), 1, 4, 4, 48, ptr(w), ptr(b), 64, 3, 3, 1, 1, None, 1, ptr(o), 0, stream_ptr()))
 
 
+@pytest.mark.parametrize('n_hyp', [3, 1, 7])
+def test_token_linear_epilogues_vs_fp32_reference(fp, n_hyp):
+  """csrc/tok_gemm.hip (every nn.Linear of the transformer heads) against torch fp32 on the same fp16-rounded operands:
+  rows (+ReLU), the transposed V image, residual + LayerNorm rows, and the LayerNorm sums over groups of 16 tokens.
+  M = 400 n: 1200 and 2800 tokens end in a ragged 128-token tile, 400 leaves the last tile 1/8 full.  The GEMM accumulates
+  in fp32, so the error is accumulation order + one fp16 rounding of the output; the LayerNorm statistics stay in fp32."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  M = 400 * n_hyp
+  g = torch.Generator().manual_seed(100 + n_hyp)
+  x = torch.randn((M, 512), generator=g).half()
+  w = (torch.randn((512, 512), generator=g) * (1.0 / 512) ** 0.5).half().float()
+  b = torch.randn((512,), generator=g) * 0.1
+  res = (torch.randn((M, 512), generator=g) * 2 + 0.5).half()
+  gam, bet = torch.rand((512,), generator=g) + 0.5, torch.randn((512,), generator=g) * 0.1
+  lin = x.float() @ w.T + b
+  x_d, res_d = x.cuda(), res.cuda()
+
+  def run(epi, relu, out, use_res=False, ln=False):
+    check(lib().fp_token_linear_f16(fp['ctx'].handle, ptr(x_d), M, ptr(w.numpy()), ptr(b.numpy()), epi, relu, ptr(res_d) if use_res else None,
+                                    ptr(gam.numpy()) if ln else None, ptr(bet.numpy()) if ln else None, 400, ptr(out), stream_ptr()))
+    return out
+  scale = float(lin.abs().max())
+  for relu in (0, 1):
+    out = run(0, relu, torch.full((M, 512), float('nan'), dtype=torch.float16, device='cuda'))
+    ref = torch.relu(lin) if relu else lin
+    assert float((out.float().cpu() - ref).abs().max()) <= 2e-3 * scale
+  # transposed V image: channel c of token t of hypothesis b at [b][c >> 7][c & 127][vt_col(t)], zero pad columns
+  vt = run(1, 0, torch.full((n_hyp, 4, 128, 416), float('nan'), dtype=torch.float16, device='cuda')).float().cpu()
+  t = np.arange(400)
+  col = (t & ~15) | (((t >> 2) & 1) << 3) | (((t >> 3) & 1) << 2) | (t & 3)
+  got_v = vt[..., torch.from_numpy(col)].permute(0, 3, 1, 2).reshape(M, 512)
+  assert float((got_v - lin).abs().max()) <= 2e-3 * scale
+  assert float(vt[..., 400:].abs().max()) == 0
+  # residual + LayerNorm (fp32 statistics on the fp32 sum)
+  y = lin + res.float()
+  ln_ref = torch.nn.functional.layer_norm(y, (512,), gam, bet, 1e-5)
+  out = run(2, 0, torch.full((M, 512), float('nan'), dtype=torch.float16, device='cuda'), use_res=True, ln=True)
+  err = float((out.float().cpu() - ln_ref).abs().max())
+  assert err <= 2.5e-3 * float(ln_ref.abs().max()), err
+  # sums of the normalised rows (no gamma / beta) over groups of 16 tokens: fp32 end to end after the MFMA
+  nrm = torch.nn.functional.layer_norm(y, (512,), None, None, 1e-5)
+  gs_ref = nrm.reshape(M // 16, 16, 512).sum(1)
+  gs = run(3, 0, torch.full((M // 16, 512), float('nan'), dtype=torch.float32, device='cuda'), use_res=True)
+  assert float((gs.cpu() - gs_ref).abs().max()) <= 2e-4 * float(gs_ref.abs().max()) + 1e-4
+  # a hypothesis' results do not depend on its place in the batch (tile alignment): bit-exact
+  if n_hyp > 1:
+    x1 = x[400:800].contiguous().cuda()
+    r1 = res[400:800].contiguous().cuda()
+    g1 = torch.empty((25, 512), dtype=torch.float32, device='cuda')
+    check(lib().fp_token_linear_f16(fp['ctx'].handle, ptr(x1), 400, ptr(w.numpy()), ptr(b.numpy()), 3, 0, ptr(r1), None, None, 400, ptr(g1), stream_ptr()))
+    assert torch.equal(g1, gs[25:50])
+
+
 @pytest.mark.parametrize('T', [400, 384, 230, 64, 37, 1])
 def test_attention_vs_reference(fp, T):
   """Fused MHA core vs softmax(QK^T/sqrt(128))V in fp32 on the same fp16 operands.  P is rounded to
