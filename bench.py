@@ -1,5 +1,6 @@
 """Benchmark: pose-hypotheses/sec of the render-and-compare hot path (render + refine x5 + score +
-argmax) on 252 hypotheses x 160x160 crops per object - BASELINE.json's metric on configs[1].
+argmax) on 252 hypotheses x 160x160 crops of ONE object - BASELINE.json's metric on configs[1] (one GPU) /
+configs[2] (the same object, its hypotheses sharded over N GPUs).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -7,9 +8,11 @@ argmax) on 252 hypotheses x 160x160 crops per object - BASELINE.json's metric on
 One "step" = one register-core pass: est_refine_iter=5 x (crop window, render,
 observed crop, RefineNet, pose update) + 1 x (crop window, render, observed crop, ScoreNet features)
 + cross-hypothesis tail + argmax, with the RGB-D frame, mesh, weights and hypotheses already resident
-in HBM.  With N GPUs the job is N objects x 252 hypotheses (weak scaling); every object's hypotheses
-are sharded over all ranks and one RCCL all-gather of [feature|pose] rows precedes the per-object
-tails (foundationpose_amd/dist.py).  Rank 0 prints ONE JSON line.
+in HBM.  With N GPUs the 252 hypotheses are cut into N contiguous shards, ONE RCCL all-gather of
+[feature|pose] rows (532 KB) precedes the cross-hypothesis tail, which every rank runs (strong scaling:
+the work is fixed, `value` = 252 x K / max-over-ranks time).  Extra keys of the JSON line: the weak-scaling
+figure (N objects x 252, fixed work per GPU), configs[3] (4 objects x 252 on the N ranks), per-rank phase
+times (local / all-gather / tail) and, on one GPU, configs[4] tracking rates.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -84,15 +87,16 @@ def step_local(est, objects, world, rank):
   return torch.cat([pack_rows(feats[offs[o]:offs[o + 1]], refined[offs[o]:offs[o + 1]], shard) for o in range(len(objects))], 0)
 
 
-def step_finalize(est, objects, world, rank, gathered):
-  """The cross-hypothesis tail of the objects this rank finalises (object o: rank o % world).  gathered: every rank's row
-  block, (world * n_objects * shard, 528) in rank order.  Returns {object: (argmax, poses (252,4,4))}."""
+def step_finalize(est, objects, world, rank, gathered, everywhere=False):
+  """The cross-hypothesis tail of the objects this rank finalises (object o: rank o % world; `everywhere`: all of them on
+  every rank).  gathered: every rank's row block, (world * n_objects * shard, 528) in rank order.
+  Returns {object: (argmax, poses (252,4,4))}."""
   from foundationpose_amd.dist import gather_order, unpack_rows
   shard = math.ceil(N_HYP / world)
   gathered = gathered.reshape(world, len(objects), shard, -1)
   results = {}
   for o in range(len(objects)):
-    if o % world != rank:
+    if not everywhere and o % world != rank:
       continue
     feats_all, poses_all = unpack_rows(gathered[gather_order(o, world), o].reshape(world * shard, -1), N_HYP, world)
     logits, am = est.scorer.score_tail(feats_all, L=N_HYP)
@@ -100,27 +104,106 @@ def step_finalize(est, objects, world, rank, gathered):
   return results
 
 
-def step(est, objects, world, rank):
-  """One register-core pass over all objects: local part, ONE all-gather of [feat | pose] rows, tail on the owning rank."""
+def step(est, objects, world, rank, replicate_tail=False, marks=None):
+  """One register-core pass over all objects: local part, ONE all-gather of [feat | pose] rows, tail on the owning rank
+  (replicate_tail: on every rank - the single-object job of configs[2], where a broadcast would cost more than 0.66 GFLOP).
+  `marks`: optional list that receives three CUDA events (after local / after gather / after tail) on the current stream."""
   from foundationpose_amd.dist import all_gather_rows
   rows = step_local(est, objects, world, rank)
-  return step_finalize(est, objects, world, rank, all_gather_rows(rows) if world > 1 else rows)
+  if marks is not None:
+    marks.append(_mark())
+  gathered = all_gather_rows(rows) if world > 1 else rows
+  if marks is not None:
+    marks.append(_mark())
+  res = step_finalize(est, objects, world, rank, gathered, everywhere=replicate_tail)
+  if marks is not None:
+    marks.append(_mark())
+  return res
+
+
+def _mark():
+  e = torch.cuda.Event(enable_timing=True)
+  e.record()
+  return e
+
+
+def timed_steps(fn, n_steps, barrier, device, world):
+  """EXACTLY n_steps calls of fn between two barriers; returns the MAX over ranks of the wall time in seconds."""
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(n_steps):
+    out = fn()
+  barrier()
+  dt = time.perf_counter() - t0
+  tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+  if world > 1:
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+  return float(tmax.item()), out
+
+
+def tracking_fps(est, device, n_frames):
+  """configs[4]: steady-state frames/s of track_one (the reference's mode: 1 hypothesis x 2 iterations, src/estimater.py:250-268)
+  and of the 64-hypothesis mode (FoundationPose.track_multi) on a synthetic sequence of `n_frames` frames along a seeded smooth
+  SE(3) trajectory (<= 1 cm, <= 2 degrees per frame), frames resident in HBM, with and without hipGraph replay of the frame."""
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.Utils import nvdiffrast_render
+  from foundationpose_amd.synthetic import trajectory
+  K = S.YCB_K
+  poses = torch.as_tensor(trajectory(n_frames), device=device)
+  g = torch.Generator(device=device).manual_seed(7)
+  rgbs, depths = [], []
+  vs, us = torch.meshgrid(torch.arange(480, device=device), torch.arange(640, device=device), indexing='ij')
+  bg = torch.stack([0.5 + 0.3 * torch.sin(us * 0.07) * torch.cos(vs * 0.05), 0.45 + 0.3 * torch.sin(us * 0.031 + vs * 0.043),
+                    0.4 + 0.25 * torch.cos(vs * 0.09 - us * 0.02)], -1)
+  for s0 in range(0, n_frames, 50):                       # rendered by the HIP rasteriser, noise added on the device
+    c, d, _ = nvdiffrast_render(K=K, H=480, W=640, ob_in_cams=poses[s0:s0 + 50], mesh_tensors=est.mesh_tensors, use_light=True)
+    m = d > 0
+    rgb = torch.where(m[..., None], c, bg[None])
+    rgb = (rgb * 255 + torch.randn(rgb.shape, device=device, generator=g) * 1.5).clamp(0, 255).to(torch.uint8)
+    dd = torch.where(m, d, torch.full_like(d, 1.2)) + torch.randn(d.shape, device=device, generator=g) * 0.001
+    dd[torch.rand(d.shape, device=device, generator=g) < 0.02] = 0
+    rgbs.append(rgb)
+    depths.append(dd)
+  rgbs, depths = torch.cat(rgbs), torch.cat(depths)
+  out = {'frames': n_frames, 'sequence': 'seeded smooth SE(3) trajectory, <= 1 cm and <= 2 deg per frame, 480x640 RGB-D frames resident in HBM'}
+  start = poses[0].clone()
+  for name, fn, n in (('track_one', lambda f: est.track_one(rgbs[f], depths[f], K, iteration=2), n_frames),
+                      ('track_multi_64', lambda f: est.track_multi(rgbs[f], depths[f], K, iteration=2, n_hypotheses=64), max(n_frames // 4, 50))):
+    for graph in (False, True):
+      est.enable_track_graph(graph)
+      est.pose_last = start.clone()
+      for f in range(10):
+        fn(f)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for f in range(n):
+        fn(f % n_frames)
+      torch.cuda.synchronize()
+      dt = time.perf_counter() - t0
+      out[name + ('_graph' if graph else '')] = {'fps': n / dt, 'ms_per_frame': dt / n * 1e3, 'frames_timed': n}
+  est.enable_track_graph(False)
+  return out
 
 
 def pmc_traffic():
-  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-  (profiles/r01_halo_traffic.json; FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected
-  as MI355X_MICROARCH.md prescribes).  None when no such profile has been committed."""
-  path = os.path.join(REPO, 'profiles', 'r01_halo_traffic.json')
-  try:
-    with open(path) as f:
-      return json.load(f)
-  except OSError:
+  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (newest
+  profiles/r*_halo_traffic.json; FETCH_SIZE / WRITE_SIZE collected in separate passes and corrected as
+  MI355X_MICROARCH.md prescribes).  None when no such profile has been committed."""
+  import glob
+  paths = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_halo_traffic.json')))
+  if not paths:
     return None
+  with open(paths[-1]) as f:
+    d = json.load(f)
+  d['file'] = os.path.relpath(paths[-1], REPO)
+  return d
 
 
 def cpu_baseline():
-  """The CPU oracle timed on this host's cores on a bounded sample of the same workload."""
+  """The CPU oracle timed on this host's cores on a bounded sample of the same workload.  Protocol: one warm-up pass on 8
+  hypotheses (thread pools, the C rasteriser's first call), then ONE timed pass on 126 hypotheses (half of configs[1]) with
+  est_refine_iter=5 + scoring - 10-15 s on 16 threads; not SURVEY 8(d)'s median-of-5 on configs[0], which measures a
+  different (32-hypothesis, 1-iteration) workload."""
   from tests import util
   from oracle.predict import OracleFoundationPose
   from foundationpose_amd import synthetic as S
@@ -130,15 +213,18 @@ def cpu_baseline():
   os.environ['OMP_NUM_THREADS'] = str(cores)
   torch.set_num_threads(cores)
   sc = util.scene(0)
-  n_s = 126            # half of the 252-hypothesis workload: 10-15 s on 16 threads
-  orc = OracleFoundationPose(sc['mt'], sc['diameter'], sc['center'], sc['grid'][:n_s], S.make_refine_state_dict(0),
-                             S.make_score_state_dict(1), refine_cfg=dict(REFINE_DEFAULT), score_cfg=dict(SCORE_DEFAULT))
+  n_s = 126
+  rsd, ssd = S.make_refine_state_dict(0), S.make_score_state_dict(1)
+  mk = lambda n: OracleFoundationPose(sc['mt'], sc['diameter'], sc['center'], sc['grid'][:n], rsd, ssd, refine_cfg=dict(REFINE_DEFAULT),
+                                      score_cfg=dict(SCORE_DEFAULT))
+  mk(8).register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=1, chunk=8)
+  orc = mk(n_s)
   t0 = time.time()
   orc.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=ITER, chunk=16)
   dt = time.time() - t0
   return dict(value=n_s / dt, unit='pose-hypotheses/sec', cores=cores, kind='port',
-              sample=f'{n_s} hypotheses of the same scene, est_refine_iter={ITER} + score, oracle/ (torch-CPU fp32 nets + C/OpenMP '
-                     f'rasteriser), {dt:.1f} s wall incl. depth filtering')
+              sample=f'{n_s} hypotheses of the same scene (half of configs[1]), est_refine_iter={ITER} + score, one timed pass after a warm-up '
+                     f'pass: oracle/ (torch-CPU fp32 nets + C/OpenMP rasteriser), {dt:.1f} s wall incl. depth filtering')
 
 
 def main():
@@ -147,6 +233,7 @@ def main():
   ap.add_argument('--steps', type=int, default=10)
   ap.add_argument('--warmup', type=int, default=2)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-extras', action='store_true', help='headline only: skip the weak-scaling / configs[3] / tracking figures')
   args = ap.parse_args()
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
@@ -168,9 +255,10 @@ def main():
     else:
       dist.init_process_group('nccl', device_id=device)
 
-  est, objects = build_job(device, n_objects=world, rank=rank)
+  n_obj = max(world, 1 if args.no_extras else 4)
+  est, objects = build_job(device, n_objects=n_obj, rank=rank)
   ctx = est.refiner.ctx
-  ctx.reserve(N_HYP)
+  ctx.reserve(max(N_HYP, 4 * math.ceil(N_HYP / world)))
 
   def barrier():
     torch.cuda.synchronize()
@@ -178,50 +266,90 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  # ---- headline = configs[1] on one GPU / configs[2] on N: ONE object, its 252 hypotheses cut into N contiguous shards, one
+  # all-gather of [feature | pose] rows, the cross-hypothesis tail + argmax replicated on every rank --------------------------
+  single = lambda: step(est, objects[:1], world, rank, replicate_tail=True)
   for _ in range(args.warmup):
-    step(est, objects, world, rank)
+    single()
   barrier()
   ctx.prof_reset()
-  ctx.prof_enable(True)          # HIP events around every dominant-kernel launch, on the launch stream
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    res = step(est, objects, world, rank)
-  barrier()
-  dt = time.perf_counter() - t0
+  ctx.prof_enable(True)          # HIP events (pooled: two records per launch) around every MFMA-kernel launch, on the launch stream
+  dt, res = timed_steps(single, args.steps, barrier, device, world)
   ctx.prof_enable(False)
   conv = ctx.prof_read('conv3x3_halo')
-  tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+  classes = {}
+  for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'render'):
+    r = ctx.prof_read(c)
+    if r['launches']:
+      classes[c] = {'ms_per_step': r['total_ms'] / args.steps, 'launches_per_step': r['launches'] / args.steps,
+                    'tflops': (r['flops'] / (r['total_ms'] * 1e-3) / 1e12) if r['flops'] else None}
+  # the same K steps with the per-launch events off (how much the events cost), and where a step's time goes on this rank
+  dt_noprof, _ = timed_steps(single, args.steps, barrier, device, world)
+  marks = []
+  t_start = _mark()
+  starts = [t_start]
+  for _ in range(min(args.steps, 5)):
+    step(est, objects[:1], world, rank, replicate_tail=True, marks=marks)
+    starts.append(marks[-1])
+  torch.cuda.synchronize()
+  n_m = len(marks) // 3
+  phases = {'local_ms': sum(starts[i].elapsed_time(marks[3 * i]) for i in range(n_m)) / n_m,
+            'allgather_ms': sum(marks[3 * i].elapsed_time(marks[3 * i + 1]) for i in range(n_m)) / n_m,
+            'tail_ms': sum(marks[3 * i + 1].elapsed_time(marks[3 * i + 2]) for i in range(n_m)) / n_m}
+  ph = torch.tensor([phases['local_ms'], phases['allgather_ms'], phases['tail_ms']], device=device, dtype=torch.float64)
+  ph_all = [torch.zeros_like(ph) for _ in range(world)]
   if world > 1:
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-  dt = float(tmax.item())
+    dist.all_gather(ph_all, ph)
+  else:
+    ph_all = [ph]
+
+  extras = {}
+  if not args.no_extras:
+    if world > 1:                # N objects x 252 on N ranks: fixed 252 hypotheses per GPU (weak scaling)
+      weak = lambda: step(est, objects[:world], world, rank)
+      for _ in range(args.warmup):
+        weak()
+      dtw, _ = timed_steps(weak, args.steps, barrier, device, world)
+      extras['weak_n_objects'] = {'objects': world, 'value': N_HYP * world * args.steps / dtw, 'unit': 'pose-hypotheses/sec',
+                                  'ms_per_step': dtw / args.steps * 1e3, 'scaling': 'weak'}
+    c3 = lambda: step(est, objects[:4], world, rank)       # configs[3]: 4 concurrent objects x 252 = 1008 hypotheses, per-object argmax
+    for _ in range(args.warmup):
+      c3()
+    dt3, _ = timed_steps(c3, args.steps, barrier, device, world)
+    extras['configs3_4x252'] = {'objects': 4, 'value': 4 * N_HYP * args.steps / dt3, 'unit': 'pose-hypotheses/sec',
+                                'ms_per_step': dt3 / args.steps * 1e3}
+    if world == 1:
+      extras['tracking_configs4'] = tracking_fps(est, device, n_frames=1000)
 
   if rank == 0:
-    total_hyp = N_HYP * world * args.steps
+    total_hyp = N_HYP * args.steps
     achieved = conv['flops'] / (conv['total_ms'] * 1e-3) / 1e12 if conv['total_ms'] > 0 else 0.0
+    traffic = pmc_traffic()
     out = {
       'metric': 'pose-hypotheses/sec (render+refine+score), 252 hyp x 160x160',
       'value': total_hyp / dt, 'unit': 'pose-hypotheses/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-      'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+      'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
       'dtype': 'f16', 'data': 'synthetic',
-      'config': {'workload': 'configs[1]: single mesh (8066 v / 16128 f), 252 hypotheses, est_refine_iter=5, 160x160 crops, '
-                             '480x640 RGB-D frame; one such object per GPU, hypotheses sharded over all ranks',
-                 'hypotheses_per_object': N_HYP, 'objects': world, 'est_refine_iter': ITER, 'parallelism': f'hyp-shard x{world}',
+      'config': {'workload': ('configs[1]' if world == 1 else 'configs[2]') + ': ONE object (mesh 8066 v / 16128 f), 252 hypotheses, '
+                             'est_refine_iter=5, 160x160 crops, 480x640 RGB-D frame' +
+                             ('' if world == 1 else f'; hypotheses cut into {world} contiguous shards of <= {math.ceil(N_HYP / world)}, one RCCL '
+                                                    f'all-gather of [feature|pose] rows, cross-hypothesis tail + argmax on every rank'),
+                 'hypotheses_per_object': N_HYP, 'objects': 1, 'est_refine_iter': ITER, 'parallelism': f'hyp-shard x{world}',
                  'weights': 'seeded random (reference state_dict layout)'},
       'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_halo_dma_kernel (3x3 stride-1 convolutions: 93 % of the conv FLOPs)',
                    'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F16_TFLOPS,
                    'avg_launch_ms': conv['total_ms'] / max(conv['launches'], 1), 'launches': conv['launches'],
                    'flops_per_launch': conv['flops'] / max(conv['launches'], 1),
-                   'traffic': (pmc_traffic() or {}).get('total'), 'traffic_detail': pmc_traffic()},
+                   'traffic': (traffic or {}).get('total') if world == 1 else None,
+                   'traffic_source': 'committed rocprofv3 PMC passes over this command at N=1 (see traffic_detail.source), not this run',
+                   'traffic_detail': traffic if world == 1 else None},
+      'ms_per_step_events_off': dt_noprof / args.steps * 1e3,
+      'phases_ms_per_rank': [dict(zip(('local', 'allgather', 'tail'), [float(x) for x in p.tolist()])) for p in ph_all],
     }
-    classes = {}
-    for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'render'):
-      r = ctx.prof_read(c)
-      if r['launches']:
-        classes[c] = {'ms_per_step': r['total_ms'] / args.steps, 'launches_per_step': r['launches'] / args.steps,
-                      'tflops': (r['flops'] / (r['total_ms'] * 1e-3) / 1e12) if r['flops'] else None}
     out['kernel_classes'] = classes       # HIP-event time per kernel class (same events as the roofline figure)
     out['kernel_classes_note'] = ('linear / attention: RefineNet runs its two transformer heads on two streams, their launches overlap '
                                   'and each counts its own span (sum > wall time); the convolution classes and render run alone')
+    out.update(extras)
     if not args.no_cpu_baseline and world == 1:        # timed on rank 0 of the single-GPU run only
       out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))

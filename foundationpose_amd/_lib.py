@@ -42,6 +42,7 @@ _PROTOS = {
   'fp_ctx_create': (c_int, [c_int, POINTER(c_void_p)]),
   'fp_ctx_destroy': (c_int, [c_void_p]),
   'fp_ctx_reserve': (c_int, [c_void_p, c_int]),
+  'fp_ctx_arena_generation': (c_int, [c_void_p]),
   'fp_mesh_create': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
   'fp_mesh_destroy': (c_int, [c_void_p]),
   'fp_crop_window_tf': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -151,6 +152,9 @@ class Context:
 
   def reserve(self, max_hyp):
     check(lib().fp_ctx_reserve(self.handle, int(max_hyp)))
+
+  def arena_generation(self):
+    return int(lib().fp_ctx_arena_generation(self.handle))
 
   def prof_enable(self, on=True):
     check(lib().fp_prof_enable(self.handle, 1 if on else 0))

@@ -53,6 +53,7 @@ int fp_arena_ensure(fp_ctx *ctx, size_t bytes) {
   a.base = (char *)p;
   a.cap = bytes;
   a.off = 0;
+  ++a.generation;
   return FP_OK;
 }
 
@@ -102,6 +103,8 @@ extern "C" int fp_ctx_destroy(fp_ctx *ctx) {
   delete ctx;
   return FP_OK;
 }
+
+extern "C" int fp_ctx_arena_generation(const fp_ctx *ctx) { return ctx ? ctx->arena.generation : -1; }
 
 extern "C" int fp_ctx_reserve(fp_ctx *ctx, int max_hyp) {
   FP_REQUIRE(ctx && max_hyp >= 1, "fp_ctx_reserve: bad argument");

@@ -360,7 +360,11 @@ int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f1
   FP_REQUIRE(T > 0 && T <= AT_MAXT, "attention: T=%d must be in [1,%d]", T, AT_MAXT);
   if (B == 0) return FP_OK;
   const size_t lds = FA_NSTAGE * FA_STAGE_HALFS * sizeof(f16);
-  FP_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  static bool attr_set = false;       // once: not a stream operation (and not wanted inside a graph capture)
+  if (!attr_set) {
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   dim3 grid(((T + FA_QB - 1) / FA_QB) * 4 * B);
   ProfScope ps(ctx, s, "attention", 4.0 * B * 4 * (double)T * T * AT_DH);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(FA_THREADS), lds, s, qk, vt, T, out, (const f16 *)ctx->zero_page);

@@ -67,6 +67,7 @@ struct PendingEvent {
 struct Arena {
   char *base = nullptr;
   size_t cap = 0, off = 0;
+  int generation = 0;      // bumped whenever the arena is (re)allocated: captured hipGraphs hold its addresses
   void *take(size_t bytes) {
     size_t o = (off + 255) & ~(size_t)255;
     if (o + bytes > cap) return nullptr;

@@ -133,19 +133,19 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
 
 // 512 x 512 row-major fp32 -> fp16 in the fragment order of tok_gemm.hip
 void pack_tok_weights(const float *w, f16 *out) {
-  for (int wave = 0; wave < 8; ++wave)
+  for (int wave = 0; wave < 4; ++wave)
     for (int k16 = 0; k16 < 32; ++k16)
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
         for (int lane = 0; lane < 64; ++lane) {
           const int lr = lane & 31, lh = lane >> 5;
-          const float *src = w + (size_t)(wave * 64 + i * 32 + lr) * 512 + k16 * 16 + lh * 8;
-          f16 *dst = out + ((((size_t)wave * 32 + k16) * 2 + i) * 64 + lane) * 8;
+          const float *src = w + (size_t)(wave * 128 + i * 32 + lr) * 512 + k16 * 16 + lh * 8;
+          f16 *dst = out + ((((size_t)wave * 32 + k16) * 4 + i) * 64 + lane) * 8;
           for (int e = 0; e < 8; ++e) dst[e] = (f16)src[e];
         }
 }
 
-// rows [r0, r0 + 512) of an (R, 512) linear weight in the MFMA-fragment order of tok_gemm.hip: [wave 8][k16 32][i 2][lane 64][8],
-// lane (lh*32 + lr) of fragment (wave, k16, i) holds W[r0 + wave*64 + i*32 + lr][k16*16 + lh*8 .. + 8] - one coalesced
+// rows [r0, r0 + 512) of an (R, 512) linear weight in the MFMA-fragment order of tok_gemm.hip: [wave 4][k16 32][i 4][lane 64][8],
+// lane (lh*32 + lr) of fragment (wave, k16, i) holds W[r0 + wave*128 + i*32 + lr][k16*16 + lh*8 .. + 8] - one coalesced
 // 1-KB load per fragment
 int make_linear(fp_net *net, const SD &sd, const std::string &wkey, const std::string &bkey, int r0, LinP *out) {
   const fp_tensor *w, *b;

@@ -182,20 +182,73 @@ class FoundationPose:
     self.pose_last = self.poses[0]
     return (self.pose_last @ self.get_tf_to_centered_mesh()).data.cpu().numpy()
 
+  # ------------------------------------------------------------------ tracking
+  def _track_frame(self, rgb, depth, K, pose_in, iteration, n_hyp, sigmas):
+    """Device work of one tracking frame, free of host synchronisation (so that it can be captured in a hipGraph): depth
+    filtering, back-projection, refinement of the previous pose (n_hyp == 1: src/estimater.py:256-266) or of n_hyp seeded
+    perturbations of it + scoring.  Returns (new pose (4,4), poses, scores, best_id) - device tensors."""
+    from .tracking import tracking_hypotheses
+    rgb = rgb.to(torch.float)
+    depth = U.bilateral_filter_depth(U.erode_depth(depth, radius=2, device='cuda'), radius=2, device='cuda')
+    # the reference back-projects with the float32 camera matrix here (depth2xyzmap_batch on a float tensor of K)
+    xyz_map = U.depth2xyzmap_batch(depth[None], np.asarray(K, dtype=np.float32)[None], zfar=np.inf)[0]
+    shared = dict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K, glctx=self.glctx, mesh_diameter=self.diameter)
+    if n_hyp == 1:
+      pose, _ = self.refiner.predict(ob_in_cams=pose_in.reshape(-1, 4, 4), normal_map=None, xyz_map=xyz_map, iteration=iteration,
+                                     get_vis=False, **shared)
+      return pose.reshape(4, 4), None, None, None
+    hyp = tracking_hypotheses(pose_in.reshape(4, 4), n_hyp, *sigmas)
+    refined, _ = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
+    scores, _ = self.scorer.predict(ob_in_cams=refined, normal_map=None, **shared)
+    best = scores.argmax()
+    return refined[best], refined, scores, best
+
+  def enable_track_graph(self, on=True):
+    """Replay a tracking frame as ONE hipGraph: at 1 .. 64 hypotheses a frame is ~100 kernels of one workgroup round or less
+    each, so launch overhead and the gaps between launches are a large part of it.  The graph is captured at the first frame of a
+    given (mode, frame size, camera, iteration count) and re-captured if the library's workspace is re-allocated."""
+    self._graph_on = bool(on)
+    self._graphs = {}
+
+  def _run_frame(self, rgb, depth, K, iteration, n_hyp, sigmas):
+    depth = torch.as_tensor(depth, device='cuda', dtype=torch.float)
+    rgb = torch.as_tensor(np.ascontiguousarray(rgb) if isinstance(rgb, np.ndarray) else rgb, device='cuda')
+    pose_in = self.pose_last.reshape(4, 4).to(torch.float)
+    if not getattr(self, '_graph_on', False):
+      return self._track_frame(rgb, depth, K, pose_in, iteration, n_hyp, sigmas)
+    ctx = self.refiner.ctx
+    key = (n_hyp, sigmas, int(iteration), tuple(rgb.shape), rgb.dtype, np.asarray(K, dtype=np.float64).tobytes(), id(self.mesh_tensors['pos']))
+    entry = self._graphs.get(key)
+    if entry is not None and entry['generation'] != ctx.arena_generation():
+      entry = None                                          # the workspace moved: the captured addresses are stale
+    if entry is None:
+      ctx.reserve(max(64, n_hyp))
+      st = dict(rgb=rgb.clone(), depth=depth.clone(), pose=pose_in.clone())
+      side = torch.cuda.Stream()
+      side.wait_stream(torch.cuda.current_stream())
+      with torch.cuda.stream(side):                          # eager passes first: lazy initialisation, allocator warm-up
+        for _ in range(2):
+          self._track_frame(st['rgb'], st['depth'], K, st['pose'], iteration, n_hyp, sigmas)
+      torch.cuda.current_stream().wait_stream(side)
+      graph = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(graph):
+        st['out'] = self._track_frame(st['rgb'], st['depth'], K, st['pose'], iteration, n_hyp, sigmas)
+      entry = self._graphs[key] = dict(graph=graph, st=st, generation=ctx.arena_generation())
+    st = entry['st']
+    st['rgb'].copy_(rgb)
+    st['depth'].copy_(depth)
+    st['pose'].copy_(pose_in)
+    entry['graph'].replay()
+    return tuple(None if t is None else t.clone() for t in st['out'])      # the static outputs are overwritten by the next replay
+
   def track_one(self, rgb, depth, K, iteration, extra={}):
     """src/estimater.py:250-268: refine the previous pose against a new frame (no scoring)."""
     if self.pose_last is None:
       logging.info("Please init pose by register first")
       raise RuntimeError
-    depth = torch.as_tensor(depth, device='cuda', dtype=torch.float)
-    rgb = torch.as_tensor(np.ascontiguousarray(rgb) if isinstance(rgb, np.ndarray) else rgb, device='cuda').to(torch.float)
-    depth = U.bilateral_filter_depth(U.erode_depth(depth, radius=2, device='cuda'), radius=2, device='cuda')
-    xyz_map = U.depth2xyzmap_batch(depth[None], torch.as_tensor(K, dtype=torch.float, device='cuda')[None], zfar=np.inf)[0]
-    pose, vis = self.refiner.predict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K,
-                                     ob_in_cams=self.pose_last.reshape(-1, 4, 4), normal_map=None, xyz_map=xyz_map,
-                                     mesh_diameter=self.diameter, glctx=self.glctx, iteration=iteration, get_vis=self.debug >= 2)
+    pose, _, _, _ = self._run_frame(rgb, depth, K, iteration, 1, None)
     if self.debug >= 2:
-      extra['vis'] = vis
+      extra['vis'] = None          # the debug canvas is outside the hot path
     self.pose_last = pose
     return (pose @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)
 
@@ -204,19 +257,10 @@ class FoundationPose:
     and never scores): the previous pose and n-1 fixed seeded perturbations of it (tracking.tracking_hypotheses) are refined
     together, scored by ScoreNet, and the best-scoring refined pose becomes `pose_last`.  Same prelude and return value as
     track_one; `self.poses` / `self.scores` hold all hypotheses of the frame in hypothesis order, `self.best_id` the winner."""
-    from .tracking import tracking_hypotheses
     if self.pose_last is None:
       logging.info("Please init pose by register first")
       raise RuntimeError
-    depth = torch.as_tensor(depth, device='cuda', dtype=torch.float)
-    rgb = torch.as_tensor(np.ascontiguousarray(rgb) if isinstance(rgb, np.ndarray) else rgb, device='cuda').to(torch.float)
-    depth = U.bilateral_filter_depth(U.erode_depth(depth, radius=2, device='cuda'), radius=2, device='cuda')
-    xyz_map = U.depth2xyzmap_batch(depth[None], torch.as_tensor(K, dtype=torch.float, device='cuda')[None], zfar=np.inf)[0]
-    hyp = tracking_hypotheses(self.pose_last.reshape(4, 4), n_hypotheses, trans_sigma, rot_sigma_deg)
-    shared = dict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K, glctx=self.glctx, mesh_diameter=self.diameter)
-    refined, _ = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
-    scores, _ = self.scorer.predict(ob_in_cams=refined, normal_map=None, **shared)
-    self.best_id = scores.argmax()
-    self.poses, self.scores = refined, scores
-    self.pose_last = refined[self.best_id]
-    return (self.pose_last @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)
+    pose, self.poses, self.scores, self.best_id = self._run_frame(rgb, depth, K, iteration, int(n_hypotheses),
+                                                                  (float(trans_sigma), float(rot_sigma_deg)))
+    self.pose_last = pose
+    return (pose @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)

@@ -27,10 +27,16 @@ def perturbation_set(n, trans_sigma=0.01, rot_sigma_deg=5.0, seed=0):
   return out.astype(np.float32)
 
 
+@functools.lru_cache(maxsize=8)
+def _device_set(n, trans_sigma, rot_sigma_deg, seed, device):
+  """The perturbation set on `device`, uploaded once (no host copy per frame: a frame can be captured in a hipGraph)."""
+  return torch.as_tensor(perturbation_set(n, trans_sigma, rot_sigma_deg, seed), device=device)
+
+
 def tracking_hypotheses(pose, n, trans_sigma=0.01, rot_sigma_deg=5.0, seed=0):
   """pose (4,4) tensor -> (n,4,4) hypotheses on its device: R_i = dR_i R, t_i = t + dt_i (the egocentric update form of
   the refiner, src/Utils.py:848-855); hypothesis 0 is `pose` itself."""
-  P = torch.as_tensor(perturbation_set(int(n), float(trans_sigma), float(rot_sigma_deg), int(seed)), device=pose.device)
+  P = _device_set(int(n), float(trans_sigma), float(rot_sigma_deg), int(seed), str(pose.device))
   pose = pose.reshape(4, 4).to(torch.float)
   hyp = torch.eye(4, dtype=torch.float, device=pose.device).repeat(n, 1, 1)
   hyp[:, :3, :3] = P[:, :3, :3] @ pose[:3, :3]

@@ -43,6 +43,9 @@ int fp_ctx_destroy(fp_ctx *ctx);
 /* Pre-size the activation arena for batches of up to `max_hyp` hypotheses so that no allocation
  * happens inside a timed / captured region. */
 int fp_ctx_reserve(fp_ctx *ctx, int max_hyp);
+/* Counts the (re)allocations of the arena.  A captured hipGraph of the launch functions holds arena addresses: it stays valid
+ * while this number does not change (reserve enough before capturing). */
+int fp_ctx_arena_generation(const fp_ctx *ctx);
 
 /* ---- mesh: make_mesh_tensors (src/Utils.py:104-130); host pointers, copied to the device ---- */
 int fp_mesh_create(fp_ctx *ctx, const float *h_pos, int V, const int32_t *h_faces, int F, const float *h_vnormals,

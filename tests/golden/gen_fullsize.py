@@ -69,7 +69,7 @@ def oracle_tracking(out, n_frames=10):
   from oracle import geometry as G, nets, predict as OP
   from tests import cases
   sc, frames = cases.tracking_frames(n_frames)
-  rsd, ssd = S.make_refine_state_dict(cases.REFINE_SEED), S.make_score_state_dict(cases.SCORE_SEED)
+  rsd, ssd = S.make_refine_state_dict(cases.REFINE_SEED, head_gain=cases.GAIN_CHAIN), S.make_score_state_dict(cases.SCORE_SEED)
   rcfg, scfg = dict(OP.DEFAULT_REFINE_CFG), dict(OP.DEFAULT_SCORE_CFG)
   t0 = time.time()
   start = torch.as_tensor(frames[0]['gt_pose']).clone()

@@ -101,3 +101,69 @@ def test_all_gather_exchange_world2():
   assert all(ok for _, _, ok, _ in res)
   for n, _ in cases:
     assert len({am for _, nn, _, am in res if nn == n}) == 1
+
+
+class _FakePredictors:
+  """CPU stand-ins with the call signatures bench.step() uses: per-hypothesis 'refinement' and 'features' that depend only on
+  the hypothesis' own pose, and a cross-hypothesis tail that needs ALL hypotheses of an object (softmax-weighted mean)."""
+
+  def predict_multi(self, objs, iteration=5):
+    return torch.cat([torch.as_tensor(o['ob_in_cams']) * (1 + 0.01 * iteration) + 0.5 for o in objs], 0)
+
+  def extract_features_multi(self, objs):
+    poses = torch.cat([torch.as_tensor(o['ob_in_cams']) for o in objs], 0).reshape(-1, 16)
+    w = torch.linspace(-1, 1, 16 * 512).reshape(16, 512)
+    return torch.tanh(poses @ w)
+
+  def score_tail(self, feats, L=None):
+    groups = feats.shape[0] // L
+    f = feats.reshape(groups, L, 512)
+    att = torch.softmax(f @ f.transpose(1, 2) / 512 ** 0.5, -1) @ f
+    logits = att.sum(-1)
+    return logits, logits.argmax(-1).to(torch.int32)
+
+
+def _bench_worker(rank, world, port, out_q):
+  sys.path.insert(0, REPO)
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  import types
+  import bench
+  fake = _FakePredictors()
+  est = types.SimpleNamespace(refiner=fake, scorer=fake, mesh_tensors=None, diameter=0.2)
+  g = torch.Generator().manual_seed(5)
+  objects = [dict(rgb=None, xyz=None, depth=None, K=None, poses=torch.randn((bench.N_HYP, 4, 4), generator=g)) for _ in range(3)]
+  # configs[2]: ONE object sharded over the ranks, tail on every rank
+  single = bench.step(est, objects[:1], world, rank, replicate_tail=True)
+  # the same object unsharded (what one GPU computes)
+  truth = bench.step(est, objects[:1], 1, 0)
+  ok_single = sorted(single) == [0] and torch.equal(single[0][1], truth[0][1]) and int(single[0][0][0]) == int(truth[0][0][0])
+  # 3 objects over the ranks (weak-scaling / configs[3] layout): each object finalised on rank o % world
+  multi = bench.step(est, objects, world, rank)
+  ok_multi = sorted(multi) == [o for o in range(3) if o % world == rank]
+  for o, (am, poses) in multi.items():
+    t = bench.step(est, objects[o:o + 1], 1, 0)[0]
+    ok_multi = ok_multi and torch.equal(poses, t[1]) and int(am[0]) == int(t[0][0])
+  out_q.put((rank, ok_single, ok_multi, int(single[0][0][0])))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_bench_step_layouts_world2():
+  """bench.py's step() over 2 gloo ranks with CPU stand-ins for the predictors: the single-object layout of configs[2] (252
+  hypotheses cut into 2 shards, one all-gather, tail replicated: every rank ends with the SAME argmax and the unsharded poses)
+  and the multi-object layout (rotated shards, object o finalised on rank o % world)."""
+  world = 2
+  ctx = mp.get_context('spawn')
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in procs:
+    p.start()
+  res = [q.get(timeout=180) for _ in range(world)]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  assert all(a and b for _, a, b, _ in res)
+  assert len({am for _, _, _, am in res}) == 1

@@ -322,6 +322,39 @@ def test_conv_rejects_bad_shapes(fp):
     check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(x), 1, 4, 4, 48, ptr(w), ptr(b), 64, 3, 3, 1, 1, None, 1, ptr(o), 0, stream_ptr()))
 
 
+def test_same_size_meshes_are_not_mistaken_for_each_other(sc):
+  """The uploaded mesh is cached per mesh_tensors OBJECTS (identity + in-place version), not per device address: two
+  different meshes of equal size rendered back to back through `mesh=` (temporary mesh_tensors whose device addresses the
+  allocator re-uses), a re-coloured copy, and an in-place edit all render their own geometry / colours."""
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.Utils import make_mesh_tensors, nvdiffrast_render
+  pose = torch.as_tensor(sc['gt_pose'])[None].cuda()
+  kw = dict(K=sc['K'], H=480, W=640, ob_in_cams=pose, use_light=True)
+  mesh_a = S.make_mustard_mesh(seed=0)
+  mesh_b = S.make_mustard_mesh(seed=0)
+  mesh_b.vertices = mesh_b.vertices * np.array([0.6, 1.3, 0.8])        # same V / F, other shape
+  mesh_c = S.make_mustard_mesh(seed=7)                                   # same shape, other colours
+  ref = {}
+  for name, m in (('a', mesh_a), ('b', mesh_b), ('c', mesh_c)):
+    mt = make_mesh_tensors(m)
+    col, dep, _ = nvdiffrast_render(mesh_tensors=mt, **kw)
+    ref[name] = (col.clone(), dep.clone())
+    del mt
+  assert not torch.equal(ref['a'][1], ref['b'][1]) and not torch.equal(ref['a'][0], ref['c'][0]) and torch.equal(ref['a'][1], ref['c'][1])
+  for _ in range(2):                                                     # temporaries built inside the call, alternating
+    for name, m in (('a', mesh_a), ('b', mesh_b), ('c', mesh_c)):
+      col, dep, _ = nvdiffrast_render(mesh=m, **kw)
+      assert torch.equal(col, ref[name][0]) and torch.equal(dep, ref[name][1]), name
+  mt = make_mesh_tensors(mesh_a)
+  col0, _, _ = nvdiffrast_render(mesh_tensors=mt, **kw)
+  mt['vertex_color'].mul_(0.5)                                           # in-place edit of a cached dict
+  col1, _, _ = nvdiffrast_render(mesh_tensors=mt, **kw)
+  assert torch.equal(col0, ref['a'][0]) and not torch.equal(col1, col0)
+  mt2 = dict(mt, pos=mt['pos'] * 1.1)                                    # shares every tensor but `pos`
+  _, dep2, _ = nvdiffrast_render(mesh_tensors=mt2, **kw)
+  assert not torch.equal(dep2, ref['a'][1])
+
+
 @pytest.mark.parametrize('n_hyp', [3, 1, 7])
 def test_token_linear_epilogues_vs_fp32_reference(fp, n_hyp):
   """csrc/tok_gemm.hip (every nn.Linear of the transformer heads) against torch fp32 on the same fp16-rounded operands:

@@ -145,8 +145,10 @@ def estimators():
   from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
   from foundationpose_amd.predict_score import ScorePredictor
   from oracle.predict import OracleFoundationPose
+  from tests import cases
   sc = util.scene(0)
-  rsd, ssd = S.make_refine_state_dict(0), S.make_score_state_dict(1)
+  # these tests chain refinement iterations (and frames): the low-gain refiner, see tests/cases.py
+  rsd, ssd = S.make_refine_state_dict(0, head_gain=cases.GAIN_CHAIN), S.make_score_state_dict(1)
   mesh = S.make_mustard_mesh(seed=0)
   refiner = PoseRefinePredictor(state_dict=rsd, cfg=REFINE_DEFAULT)
   scorer = ScorePredictor(state_dict=ssd, cfg=SCORE_DEFAULT)
@@ -346,7 +348,7 @@ def test_predictors_other_config_branches(variant):
   if variant == 'plain_xyz_tanh':
     rcfg = dict(REFINE_DEFAULT, normalize_xyz=False)
     scfg = dict(SCORE_DEFAULT, normalize_xyz=False)
-    rsd, ssd = S.make_refine_state_dict(0), S.make_score_state_dict(1)
+    rsd, ssd = S.make_refine_state_dict(0, head_gain=0.1), S.make_score_state_dict(1)      # two chained iterations: low gain
   else:
     rcfg = dict(REFINE_DEFAULT, rot_rep='6d', use_BN=False)
     scfg = dict(SCORE_DEFAULT, use_BN=False)
