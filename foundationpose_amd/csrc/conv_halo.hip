@@ -7,10 +7,9 @@
 //   * brings the input rows it needs ONCE into LDS (the "halo band") and feeds all 9 taps from it: a tap shift is just a
 //     different LDS address per lane (+-1 pixel, +-1 row; taps outside the image select a zero chunk),
 //   * streams the 3 taps of one kernel row of weights at a time (128 co x 32 ci x 3 = 24 KB, double buffered) by LDS-DMA.
-// Two forms live in this file (v_mfma_f32_32x32x16_f16 both, identical results):
-//   conv3x3_halo_dma_kernel  DEFAULT: 8 waves, 512 px, band by LDS-DMA (double buffered);
-//   conv3x3_halo_kernel      FP_HALO_FORM=1: 4 or 8 waves (FP_HALO_NPW), band through registers + ds_write
-//                            (also carries the in-kernel cycle stamps of the diagnostic build, make -B EXTRA=-DHALO_STAMP).
+// conv3x3_halo_dma_kernel: 8 waves, 512 px, band by LDS-DMA (double buffered), v_mfma_f32_32x32x16_f16.  Diagnostic builds
+// (make -B EXTRA=-DHALO_STAMP, never shipped) also hold the earlier register-staged form conv3x3_halo_kernel (4 or 8 waves,
+// FP_HALO_FORM=1 / FP_HALO_NPW) that carries the in-kernel cycle stamps; identical results.
 // Epilogue: accumulators start at the bias; residual (staged through LDS) + ReLU (+ positional embedding) in fp32, one
 // rounding to fp16, LDS transpose, 16-byte row-contiguous NHWC stores.
 #include "common.h"
@@ -46,6 +45,7 @@ struct IC {
   static constexpr int value = V;
 };
 
+#ifdef HALO_STAMP      // the register-staged form exists in diagnostic builds only (it carries the in-kernel cycle stamps)
 template <int W, int TM>
 struct HaloCfg {
   static constexpr int MAXSLOT = (W - 1 + TM - 1) / W + 1 + 2;     // input rows a TM-pixel run can touch (+1 above, +1 below)
@@ -59,6 +59,7 @@ struct HaloCfg {
   static constexpr int LDS_BYTES = 2 * (LDS_HALFS_MAIN > LDS_HALFS_EPI ? LDS_HALFS_MAIN : LDS_HALFS_EPI);
 };
 
+#endif
 // LDS-DMA issued from inline asm.  Through __builtin_amdgcn_global_load_lds the compiler marks a "flat access that may
 // touch LDS" as pending until the next full drain, and while that mark is up EVERY wait it inserts for an LDS fragment read
 // is s_waitcnt lgkmcnt(0) (and every barrier drains vmcnt(0)) - no LDS read can stay in flight under the MFMAs.  Hidden in
@@ -69,6 +70,7 @@ __device__ __forceinline__ void glds16(const f16 *sbase, unsigned voff_bytes, f1
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(sbase), "s"(la) : "memory");
 }
 
+#ifdef HALO_STAMP
 // One workgroup tile: 2 NPW waves as 2 (cout halves) x NPW (pixel columns); each wave 64 co x 32*NT px (2 x NT accumulator
 // tiles), i.e. 128 couts x 32*NT*NPW pixels per workgroup.  NT = 4 -> main tiles, NT = 1 -> tail tiles.  The accumulation
 // order of every output element (chunk, ky, kx, k-step) does not depend on NT / NPW: the tile shape never changes a bit.
@@ -389,6 +391,7 @@ __device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const
   })
 }
 
+#endif   // HALO_STAMP
 // ------------------------------------------------------------------------------------------------------------------------
 // DEFAULT FORM.  8-wave tile (512 px x 128 co, one workgroup per CU) with the halo band staged by LDS-DMA as well, double
 // buffered:
@@ -718,6 +721,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, in
 }
 
 
+#ifdef HALO_STAMP
 // Grid = n_main workgroups of 128 NPW px x 128 co, then n_tail4 workgroups of 32 NPW px x 128 co covering the LAST main-size
 // tiles cut in four.  A launch has (workgroups per CU) x 256 slots; at N=252 every layer of the network has 3150 or 1576
 // 256-pixel tiles, i.e. a last round that is 8-15 % full - cutting only that remainder into quarters lets the round end
@@ -744,13 +748,17 @@ __global__ __launch_bounds__(128 * NPW, NPW == 2 ? 2 : 1) void conv3x3_halo_kern
   }
 }
 
+#endif   // HALO_STAMP
+
 bool conv_halo_supported(const ConvArgs &a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H == a.W && (a.W == 40 || a.W == 20) && a.Cin % HL_CK == 0 &&
          a.Cout % HL_BM == 0 && a.out_mode == 0 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0;
 }
 
 int g_halo_tail = 1;   // FP_HALO_TAIL=0 disables the tail split (A/B timing only; results are identical)
-int g_halo_npw = 4;    // FP_HALO_NPW=2 selects the 4-wave / 2-workgroups-per-CU form (A/B timing only; results are identical)
+int g_halo_form = 0;   // diagnostic builds only, FP_HALO_FORM: 0 = band by LDS-DMA, 8 waves (default); 1 = band through registers, FP_HALO_NPW x 2 waves
+                       // (A/B timing; identical results: same MFMA shape and accumulation order)
+int g_halo_npw = 4;    // diagnostic builds: FP_HALO_NPW=2 selects the 4-wave / 2-workgroups-per-CU form (A/B timing only; results are identical)
 
 // main/tail split: whole rounds of `slots` main tiles stay; the remainder is cut in four when that shortens the last round
 // (a quarter tile costs ~0.35 of a main tile: less operand reuse), i.e. when the remainder fills < ~70 % of a round.
@@ -775,6 +783,7 @@ void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
   }
 }
 
+#ifdef HALO_STAMP
 template <int W, int NPW, bool RES, bool POST>
 static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
   constexpr int TMM = 128 * NPW;
@@ -802,14 +811,14 @@ static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
   return FP_OK;
 }
 
-int g_halo_form = 0;   // FP_HALO_FORM: 0 = band by LDS-DMA, 8 waves (default); 1 = band through registers, FP_HALO_NPW x 2 waves
-                       // (A/B timing; identical results: same MFMA shape and accumulation order)
 
 template <int W, int NPW>
 static int launch_halo_flags(const ConvArgs &a, hipStream_t s) {
   if (a.post_add) return a.res ? launch_halo_w<W, NPW, true, true>(a, s) : launch_halo_w<W, NPW, false, true>(a, s);
   return a.res ? launch_halo_w<W, NPW, true, false>(a, s) : launch_halo_w<W, NPW, false, false>(a, s);
 }
+
+#endif   // HALO_STAMP
 
 template <int W, bool RES, bool POST>
 static int launch_halo_dma(const ConvArgs &a, hipStream_t s) {
@@ -841,7 +850,11 @@ static int launch_halo_dma_flags(const ConvArgs &a, hipStream_t s) {
 int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
   // lane offsets into the input tensor are 32-bit byte offsets from its base
   FP_REQUIRE((double)a.M * a.Cin * 2.0 < 4294967296.0, "conv3x3: input tensor of %.1f GB exceeds the 4 GB the kernel addresses", (double)a.M * a.Cin * 2e-9);
-  if (g_halo_form == 0) return a.W == 40 ? launch_halo_dma_flags<40>(a, s) : launch_halo_dma_flags<20>(a, s);
-  if (g_halo_npw == 2) return a.W == 40 ? launch_halo_flags<40, 2>(a, s) : launch_halo_flags<20, 2>(a, s);
-  return a.W == 40 ? launch_halo_flags<40, 4>(a, s) : launch_halo_flags<20, 4>(a, s);
+#ifdef HALO_STAMP
+  if (g_halo_form != 0) {
+    if (g_halo_npw == 2) return a.W == 40 ? launch_halo_flags<40, 2>(a, s) : launch_halo_flags<20, 2>(a, s);
+    return a.W == 40 ? launch_halo_flags<40, 4>(a, s) : launch_halo_flags<20, 4>(a, s);
+  }
+#endif
+  return a.W == 40 ? launch_halo_dma_flags<40>(a, s) : launch_halo_dma_flags<20>(a, s);
 }

@@ -389,13 +389,17 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, (int4 *)a.vbuf);
     FP_CHECK_HIP(hipGetLastError());
   }
-  auto go = [&](auto kern) -> int {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto go = [&](auto kern, bool *attr_set) -> int {
+    if (!*attr_set) {              // once per instantiation, for the largest strip: not a stream operation
+      FP_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+      *attr_set = true;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(RB_THREADS), lds, s, a, strip_rows, n_strips, vbuf);
     return FP_OK;
   };
-  if (a.net_out) FP_TRY(vbuf ? go(render_kernel<1, true>) : go(render_kernel<1, false>));
-  else FP_TRY(vbuf ? go(render_kernel<0, true>) : go(render_kernel<0, false>));
+  static bool set11 = false, set10 = false, set01 = false, set00 = false;
+  if (a.net_out) FP_TRY(vbuf ? go(render_kernel<1, true>, &set11) : go(render_kernel<1, false>, &set10));
+  else FP_TRY(vbuf ? go(render_kernel<0, true>, &set01) : go(render_kernel<0, false>, &set00));
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -131,7 +131,7 @@ def stage_track():
   np.savez(CACHE, **out)
 
 
-def stage_tail(n_seeds=4000):
+def stage_tail(n_seeds=1500):
   from foundationpose_amd import synthetic as S
   from tests import cases
   z = np.load(CACHE)

@@ -495,14 +495,3 @@ def test_register_prelude_on_device(sc, fp, golden):
   z = np.zeros_like(dfull)
   st = U.mask_depth_stats(torch.from_numpy(z).cuda(), sc['mask'])
   assert st['n_usable'] == 0 and st['n_mask'] == sc['mask'].sum() and st['median'] == 0
-
-
-@pytest.mark.parametrize('npw', ['2', '4'])
-def test_register_staged_form_of_the_3x3_kernel(npw):
-  """The alternative form of the 3x3 kernel kept in the tree (FP_HALO_FORM=1: band through registers, 4 or 8 waves) passes
-  the same convolution parity cases.  The form is chosen when the context is created, hence the child process."""
-  import os, subprocess, sys
-  env = dict(os.environ, FP_HALO_FORM='1', FP_HALO_NPW=npw)
-  r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k', 'test_conv_igemm_vs_fp32_reference'],
-                     env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
