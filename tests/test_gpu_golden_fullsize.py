@@ -213,7 +213,7 @@ def test_trk_64_hypotheses_per_frame(full, tracker):
   within noise, the same winner.  Every frame starts from the ORACLE's previous winner on both sides (teacher forcing), so
   that a frame is judged on its own."""
   est, sc, frames = tracker
-  for f, fr in enumerate(frames):
+  for f, fr in enumerate(frames[:len(full['trk/multi_in'])]):
     est.pose_last = torch.as_tensor(full['trk/multi_in'][f][0]).cuda()
     est.track_multi(rgb=fr['rgb'], depth=fr['depth'], K=fr['K'], iteration=2, n_hypotheses=64)
     err = float(np.abs(est.poses.cpu().numpy() - full['trk/multi_poses'][f]).max())
