@@ -273,10 +273,15 @@ def main():
     single()
   barrier()
   ctx.prof_reset()
-  ctx.prof_enable(True)          # HIP events (pooled: two records per launch) around every MFMA-kernel launch, on the launch stream
-  dt, res = timed_steps(single, args.steps, barrier, device, world)
+  ctx.prof_enable(1)             # HIP events (pooled: two records per launch) around the launches of the DOMINANT kernel class, on the
+  dt, res = timed_steps(single, args.steps, barrier, device, world)       # launch stream: the roofline figure comes from the timed region
   ctx.prof_enable(False)
   conv = ctx.prof_read('conv3x3_halo')
+  # every kernel class: a separate, untimed pass of the same steps (events around all ~160 launches of a step cost 2 % of it)
+  ctx.prof_reset()
+  ctx.prof_enable(2)
+  timed_steps(single, args.steps, barrier, device, world)
+  ctx.prof_enable(False)
   classes = {}
   for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'render'):
     r = ctx.prof_read(c)
@@ -346,7 +351,7 @@ def main():
       'ms_per_step_events_off': dt_noprof / args.steps * 1e3,
       'phases_ms_per_rank': [dict(zip(('local', 'allgather', 'tail'), [float(x) for x in p.tolist()])) for p in ph_all],
     }
-    out['kernel_classes'] = classes       # HIP-event time per kernel class (same events as the roofline figure)
+    out['kernel_classes'] = classes       # HIP-event time per kernel class, from an untimed pass of the same K steps
     out['kernel_classes_note'] = ('linear / attention: RefineNet runs its two transformer heads on two streams, their launches overlap '
                                   'and each counts its own span (sum > wall time); the convolution classes and render run alone')
     out.update(extras)

@@ -157,7 +157,8 @@ class Context:
     return int(lib().fp_ctx_arena_generation(self.handle))
 
   def prof_enable(self, on=True):
-    check(lib().fp_prof_enable(self.handle, 1 if on else 0))
+    """False / 0: off; 1: events around the dominant kernel class only; True / 2: around every class."""
+    check(lib().fp_prof_enable(self.handle, 2 if on is True else int(on)))
 
   def prof_reset(self):
     check(lib().fp_prof_reset(self.handle))

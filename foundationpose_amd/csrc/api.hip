@@ -127,7 +127,7 @@ extern "C" int fp_ctx_reserve(fp_ctx *ctx, int max_hyp) {
 // ---- profiling ---------------------------------------------------------------------------------
 extern "C" int fp_prof_enable(fp_ctx *ctx, int on) {
   FP_REQUIRE(ctx, "fp_prof_enable: null ctx");
-  ctx->prof = on != 0;
+  ctx->prof = on < 0 ? 0 : (on > 2 ? 2 : on);
   return FP_OK;
 }
 

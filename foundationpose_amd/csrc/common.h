@@ -80,7 +80,7 @@ struct fp_ctx {
   int device = 0;
   Arena arena;
   int reserved_hyp = 0;
-  bool prof = false;
+  int prof = 0;            // 0 off, 1 events around the dominant kernel class only (3x3 stride-1 convolutions), 2 around every class
   std::map<std::string, ProfEntry> prof_tab;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> ev_pool;   // recycled timing events: a profiled launch costs two hipEventRecord, no create / destroy
@@ -150,7 +150,8 @@ struct ProfScope {
   hipStream_t s;
   PendingEvent ev;
   bool on;
-  ProfScope(fp_ctx *c, hipStream_t st, const char *cls, double flops) : ctx(c), s(st), on(c && c->prof) {
+  ProfScope(fp_ctx *c, hipStream_t st, const char *cls, double flops)
+      : ctx(c), s(st), on(c && (c->prof == 2 || (c->prof == 1 && strcmp(cls, "conv3x3_halo") == 0))) {
     if (on) {
       ev.a = take_event();
       ev.b = take_event();

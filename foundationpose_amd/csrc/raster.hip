@@ -141,11 +141,11 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     return o;
   };
 
-  // ---- pass 1: stream triangles, resolve visibility in LDS ----
-  for (int t = threadIdx.x; t < m.F; t += RB_THREADS) {
-    int i0 = m.faces[t * 3], i1 = m.faces[t * 3 + 1], i2 = m.faces[t * 3 + 2];
-    Vtx v0 = vertex(i0), v1 = vertex(i1), v2 = vertex(i2);
-    if (!(v0.ok && v1.ok && v2.ok)) continue;
+  // ---- pass 1: stream triangles, resolve visibility in LDS.  Four triangles per thread are in flight at a time: their index
+  // and vertex loads (two dependent memory round trips) are issued together - at 1 .. 64 hypotheses a workgroup is alone on
+  // its CU and the loop is latency-bound (tracking: 86 -> see DESIGN.md us per render); coverage and keys do not depend on order.
+  auto raster_tri = [&](const int t, const Vtx &v0, const Vtx &v1, const Vtx &v2) __attribute__((always_inline)) {
+    if (!(v0.ok && v1.ok && v2.ok)) return;
     // Triangles whose snapped coordinates stay within +-1024 px (all but the ones far outside the crop) take the same
     // integer edge functions in 32-bit arithmetic: |X|,|Y| < 2^14 -> differences < 2^15, products < 2^30, sums < 2^31.
     // The values are the same integers as in the 64-bit path, so coverage, barycentrics and depth keys are bit-identical.
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     if (amax < 16384) {
       const int X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
       int area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
-      if (area == 0) continue;
+      if (area == 0) return;
       const int sg = area > 0 ? 1 : -1;
       area *= sg;
       const int xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
       ja = max(ja, row0);
       ib = min(ib, Wo - 1);
       jb = min(jb, row1 - 1);
-      if (ia > ib || ja > jb) continue;
+      if (ia > ib || ja > jb) return;
       const int dx0 = sg * (X2 - X1), dy0 = sg * (Y2 - Y1);
       const int dx1 = sg * (X0 - X2), dy1 = sg * (Y0 - Y2);
       const int dx2 = sg * (X1 - X0), dy2 = sg * (Y1 - Y0);
@@ -186,11 +186,11 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
           atomicMin(&zbuf[(j - row0) * Wo + i], key);
         }
       }
-      continue;
+      return;
     }
     long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
     long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
-    if (area == 0) continue;
+    if (area == 0) return;
     long long sg = area > 0 ? 1 : -1;
     area *= sg;
     long long xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     ja = max(ja, (long long)row0);
     ib = min(ib, (long long)Wo - 1);
     jb = min(jb, (long long)row1 - 1);
-    if (ia > ib || ja > jb) continue;
+    if (ia > ib || ja > jb) return;
     long long dx0 = sg * (X2 - X1), dy0 = sg * (Y2 - Y1);
     long long dx1 = sg * (X0 - X2), dy1 = sg * (Y0 - Y2);
     long long dx2 = sg * (X1 - X0), dy2 = sg * (Y1 - Y0);
@@ -223,6 +223,23 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
         atomicMin(&zbuf[(int)(j - row0) * Wo + (int)i], key);
       }
     }
+  };
+  for (int t0 = threadIdx.x; t0 < m.F; t0 += 4 * RB_THREADS) {
+    int fi[4][3];
+    Vtx fv[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(t0 + u * RB_THREADS, m.F - 1);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fi[u][k] = m.faces[t * 3 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fv[u][k] = vertex(fi[u][k]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (t0 + u * RB_THREADS < m.F) raster_tri(t0 + u * RB_THREADS, fv[u][0], fv[u][1], fv[u][2]);
   }
   __syncthreads();
 
@@ -380,6 +397,9 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s) {
   FP_REQUIRE(strip_rows >= 1, "render: output width %d too large for one LDS strip", a.Wo);
   if (strip_rows > a.Ho) strip_rows = a.Ho;
   int n_strips = (a.Ho + strip_rows - 1) / strip_rows;
+  // a handful of hypotheses (tracking): more, thinner strips - the per-pixel resolve pass of a workgroup shrinks with its strip
+  // and the launch still fits one round of workgroups (a pixel's result does not depend on the strip it is in)
+  while (a.N * n_strips * 2 <= ctx->num_cu / 2 && n_strips < 8 && a.Ho / (n_strips * 2) >= 8) n_strips *= 2;
   strip_rows = (a.Ho + n_strips - 1) / n_strips;  // balance
   size_t lds = (size_t)strip_rows * a.Wo * 8;
   dim3 grid((unsigned)(a.N * n_strips));

@@ -201,7 +201,7 @@ class FoundationPose:
     refined, _ = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
     scores, _ = self.scorer.predict(ob_in_cams=refined, normal_map=None, **shared)
     best = scores.argmax()
-    return refined[best], refined, scores, best
+    return refined.index_select(0, best.reshape(1))[0], refined, scores, best      # (indexing by a 0-d tensor would synchronise)
 
   def enable_track_graph(self, on=True):
     """Replay a tracking frame as ONE hipGraph: at 1 .. 64 hypotheses a frame is ~100 kernels of one workgroup round or less

@@ -197,8 +197,9 @@ int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const float *h_wei
 int fp_cluster_poses(float angle_diff_deg, float dist_diff_m, const float *h_poses_in, int n_in, const float *h_symmetry_tfs,
                      int n_sym, float *h_out);
 
-/* timing helper: average device time (ms) of the dominant conv kernel class over the launches since
- * the last reset, measured with HIP events on the launch stream when profiling is enabled. */
+/* timing helper: device time of a kernel class ("conv3x3_halo", "conv3x3_s2", "conv7x7", "linear", "attention", "render") over
+ * the launches since the last reset, measured with (pooled) HIP events on the launch stream.  on = 0: off; 1: events around the
+ * dominant class only (the 3x3 stride-1 convolutions: what a timed benchmark run carries); 2: around every class. */
 int fp_prof_enable(fp_ctx *ctx, int on);
 int fp_prof_read(fp_ctx *ctx, const char *kernel_class, double *total_ms, int64_t *launches, double *flops);
 int fp_prof_reset(fp_ctx *ctx);
