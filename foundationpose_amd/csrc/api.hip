@@ -27,7 +27,7 @@ size_t fp_arena_bytes_for(int n_hyp) {
 size_t fp_arena_inner_bytes(int n_hyp) {
   // exact sum of the forward's buffers is 11,485,184 B per hypothesis (DESIGN.md "HBM layout")
   // + 2.9 MB per hypothesis for the second transformer head's buffers (the two heads of RefineNet run side by side)
-  return (size_t)n_hyp * (size_t)(15u << 20) + ((size_t)8 << 20);
+  return (size_t)n_hyp * (size_t)(15u << 20) + ((size_t)8 << 20) + (n_hyp <= 4 ? ((size_t)40 << 20) : 0);   // + split-K scratch (1 .. 4 hypotheses)
 }
 
 int fp_arena_ensure(fp_ctx *ctx, size_t bytes) {
@@ -550,6 +550,8 @@ extern "C" int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const f
   return fp_score_predict_features_multi(ctx, net, &ob, 1, crop_ratio, normalize_xyz, d_poses, d_feats, stream);
 }
 
+int conv_halo_ksplit(const ConvArgs &a, int num_cu);      // conv_halo.hip
+
 // ---- building blocks ---------------------------------------------------------------------------------
 extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin, const void *d_w_packed, const float *d_bias,
                              int Cout, int KH, int KW, int stride, int pad, const void *d_res, int relu, void *d_out, int out_f32,
@@ -582,6 +584,18 @@ extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int
   a.split_m = 0x7fffffff;
   a.post_period = 1;
   a.tokens = 400;
+  // launches of a few workgroups take the split-K form of the 3x3 stride-1 kernel, as inside the networks (1 .. 4 hypotheses)
+  a.ksplit = out_f32 ? 0 : conv_halo_ksplit(a, ctx->num_cu);
+  if (a.ksplit > 1) {
+    const size_t bytes = (size_t)a.ksplit * a.M * a.Cout * sizeof(float);
+    FP_TRY(fp_arena_ensure(ctx, bytes + 4096));
+    const size_t mark = ctx->arena.off;
+    a.splitk = (float *)ctx->arena.take(bytes);
+    int rc = a.splitk ? launch_conv(ctx, a, (hipStream_t)stream) : FP_ENOMEM;
+    ctx->arena.off = mark;        // the scratch is consumed by the finishing pass on the same stream before anything else takes it
+    return rc;
+  }
+  a.ksplit = 0;
   return launch_conv(ctx, a, (hipStream_t)stream);
 }
 

@@ -200,6 +200,11 @@ struct ConvArgs {
   int Nimg, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, Kpad, M;
   int relu, out_mode;  // 0 fp16 NHWC, 1 fp32 NHWC, 2 fp16 V-transposed [b][4][128][416], token t in column vt_col(t)
   int out_ld, split_m, coff_hi, post_period, tokens;
+  // split-K of the 3x3 stride-1 kernel for launches of a few workgroups (1 .. 4 hypotheses: tracking): `ksplit` workgroups share
+  // the input-channel chunks of a tile and leave fp32 partial sums in `splitk` [ksplit][M][Cout]; a finishing pass adds them in a
+  // fixed order and applies bias-free epilogue (the bias rides in split 0).  0 / nullptr: off.
+  float *splitk = nullptr;
+  int ksplit = 0;
 };
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 

@@ -421,8 +421,8 @@ struct HaloCfgD {
   static constexpr int LDS_BYTES = 2 * (LDS_HALFS_MAIN > LDS_HALFS_EPI ? LDS_HALFS_MAIN : LDS_HALFS_EPI);
 };
 
-template <int W, int NT, bool RES, bool POST>
-__device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, const int c0, f16 *lds) {
+template <int W, int NT, bool RES, bool POST, bool SPLIT = false>
+__device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, const int c0, f16 *lds, const int ks = 0) {
   constexpr int NPW = 4, TM = 32 * NT * NPW;
   using C = HaloCfgD<W, TM>;
   constexpr int H = W;
@@ -437,7 +437,10 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
   const int lr = lane & 31, lh = lane >> 5;
   const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by band row 0
   const int total_rows = p.Nimg * H;
-  const int nchunk = p.Cin / HL_CK;
+  // input-channel chunks [cbeg, nchunk) of this workgroup: all of them, or (SPLIT) share ks of p.ksplit equal shares
+  const int call = p.Cin / HL_CK;
+  const int cbeg = SPLIT ? ks * (call / p.ksplit) : 0;
+  const int nchunk = SPLIT ? cbeg + call / p.ksplit : call;
 
   // ---- B fragments: band index of the top-left tap of this lane's pixel in tile 0 (tile j, taps: see load_b) ----
   const int pb = m0 + wn * PXW + lr - GR0 * W - W;
@@ -494,7 +497,8 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
+      float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
+      if (SPLIT && ks != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);       // the bias rides in split 0
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         acc[i][j][rg * 4 + 0] = bv.x;
@@ -507,15 +511,15 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
   if (tid < 1) *reinterpret_cast<u32x4 *>(&lds[C::ZERO_OFF]) = u32x4{0, 0, 0, 0};
   {
     auto all = [&](auto hc) __attribute__((always_inline)) {
-      if constexpr (decltype(hc)::value < HQ) halo_dma(0, 0, hc);
+      if constexpr (decltype(hc)::value < HQ) halo_dma(cbeg, cbeg & 1, hc);
     };
     all(IC<0>{}), all(IC<1>{}), all(IC<2>{}), all(IC<3>{}), all(IC<4>{}), all(IC<5>{}), all(IC<6>{}), all(IC<7>{});
     static_assert(HQ <= 8, "extend the list");
   }
-  wstage(0, 0, 0, IC<0>{}, IC<WQ>{});
+  wstage(cbeg, 0, 0, IC<0>{}, IC<WQ>{});
   int g = 0;
   STAMP(unsigned long long t_wait = 0; unsigned long long t_body = 0; unsigned long long t_prev = __builtin_amdgcn_s_memtime();)
-  for (int cc = 0; cc < nchunk; ++cc) {
+  for (int cc = cbeg; cc < nchunk; ++cc) {
     const f16 *halo = lds + (cc & 1) * C::HBUF_HALFS;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky, ++g) {
@@ -608,6 +612,22 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
   }
   STAMP(const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();)
 
+  if constexpr (SPLIT) {
+    // fp32 partial sums of this share -> p.splitk[ks][m][Cout] (16-byte stores in the accumulator layout); splitk_finish adds
+    // the shares in a fixed order and applies residual / ReLU / positional embedding
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int m = m0 + wn * PXW + j * 32 + lr;
+      if (m >= p.M) continue;
+      float *o = p.splitk + ((size_t)ks * p.M + m) * p.Cout + c0 + wm * 64 + lh * 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *reinterpret_cast<float4 *>(o + i * 32 + rg * 8) = make_float4(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]);
+    }
+    return;
+  }
   // ---------------- epilogue (as in halo_tile) ----------------
   f16 *stage = lds;   // [TM px][HL_SLD]
   constexpr int NRES = TM * 16 / NTH;
@@ -720,6 +740,46 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, in
   }
 }
 
+
+// Split-K form for launches of a few workgroups (1 .. 4 hypotheses): every tile is a 128-pixel quarter tile, p.ksplit workgroups
+// per tile each take an equal share of the input-channel chunks.  At one hypothesis a 512-channel layer is 16 workgroups that
+// each walk 48 weight groups behind one DMA round trip apiece (40 us); four shares of 12 groups + the finishing pass take a third.
+template <int W>
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_splitk_kernel(ConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) f16 lds[];
+  const int n_ct = p.Cout / HL_BM;
+  const int ks = blockIdx.x % p.ksplit, t = blockIdx.x / p.ksplit;
+  const int m0 = (t / n_ct) * 128;
+  if (m0 >= p.M) return;
+  halo_tile_dma<W, 1, false, false, true>(p, m0, (t % n_ct) * HL_BM, lds, ks);
+}
+
+// out = [+ pos.emb.] relu?( sum_ks partial[ks] [+ residual] ), one thread per pixel x 4 channels, shares added in order
+__global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
+  const int q = blockIdx.x * 256 + threadIdx.x, c4 = p.Cout / 4;
+  if (q >= p.M * c4) return;
+  const int m = q / c4, c = (q - m * c4) * 4;
+  float4 v = *reinterpret_cast<const float4 *>(p.splitk + (size_t)m * p.Cout + c);
+  for (int ks = 1; ks < p.ksplit; ++ks) {
+    const float4 w = *reinterpret_cast<const float4 *>(p.splitk + ((size_t)ks * p.M + m) * p.Cout + c);
+    v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+  }
+  if (p.res) {
+    const half4 r = *reinterpret_cast<const half4 *>(p.res + (size_t)m * p.Cout + c);
+    v.x += (float)r[0], v.y += (float)r[1], v.z += (float)r[2], v.w += (float)r[3];
+  }
+  const float lo = p.relu ? 0.f : -__builtin_inff();
+  v.x = fmaxf(v.x, lo), v.y = fmaxf(v.y, lo), v.z = fmaxf(v.z, lo), v.w = fmaxf(v.w, lo);
+  if (p.post_add) {
+    const float4 pv = *reinterpret_cast<const float4 *>(p.post_add + (size_t)(m % p.post_period) * p.Cout + c);
+    v.x += pv.x, v.y += pv.y, v.z += pv.z, v.w += pv.w;
+  }
+  half4 hv;
+  hv[0] = (f16)v.x, hv[1] = (f16)v.y, hv[2] = (f16)v.z, hv[3] = (f16)v.w;
+  const bool hi = m >= p.split_m;
+  const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+  *reinterpret_cast<half4 *>((f16 *)p.out + orow * p.out_ld + (hi ? p.coff_hi : 0) + c) = hv;
+}
 
 #ifdef HALO_STAMP
 // Grid = n_main workgroups of 128 NPW px x 128 co, then n_tail4 workgroups of 32 NPW px x 128 co covering the LAST main-size
@@ -847,9 +907,39 @@ static int launch_halo_dma_flags(const ConvArgs &a, hipStream_t s) {
   return a.res ? launch_halo_dma<W, true, false>(a, s) : launch_halo_dma<W, false, false>(a, s);
 }
 
+template <int W>
+static int launch_halo_splitk(const ConvArgs &a, hipStream_t s) {
+  using C = HaloCfgD<W, 128>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_splitk_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    attr_set = true;
+  }
+  const int n_q = ((a.M + 127) / 128) * (a.Cout / HL_BM);
+  hipLaunchKernelGGL((conv3x3_halo_splitk_kernel<W>), dim3(n_q * a.ksplit), dim3(512), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((a.M * (a.Cout / 4) + 255) / 256), dim3(256), 0, s, a);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+// Split factor for a launch of this shape: 0 unless the quarter tiles fill at most a quarter of the CUs (1 .. 4 hypotheses);
+// then as many shares as keep >= 2 chunks per share and the grid within the chip.  Decided by the caller that owns the scratch.
+int conv_halo_ksplit(const ConvArgs &a, int num_cu) {
+  if (!conv_halo_supported(a)) return 0;
+  const int n_q = ((a.M + 127) / 128) * (a.Cout / HL_BM), nchunk = a.Cin / HL_CK;
+  if (n_q * 4 > num_cu) return 0;
+  int k = 4;
+  while (k > 1 && (nchunk % k != 0 || nchunk / k < 2 || n_q * k > num_cu)) k >>= 1;
+  return k > 1 ? k : 0;
+}
+
 int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
   // lane offsets into the input tensor are 32-bit byte offsets from its base
   FP_REQUIRE((double)a.M * a.Cin * 2.0 < 4294967296.0, "conv3x3: input tensor of %.1f GB exceeds the 4 GB the kernel addresses", (double)a.M * a.Cin * 2e-9);
+  if (a.splitk && a.ksplit > 1) {
+    FP_REQUIRE((a.Cin / HL_CK) % a.ksplit == 0 && a.out_ld % 4 == 0 && a.coff_hi % 4 == 0, "conv3x3 split-K: %d shares do not divide %d chunks", a.ksplit, a.Cin / HL_CK);
+    return a.W == 40 ? launch_halo_splitk<40>(a, s) : launch_halo_splitk<20>(a, s);
+  }
 #ifdef HALO_STAMP
   if (g_halo_form != 0) {
     if (g_halo_npw == 2) return a.W == 40 ? launch_halo_flags<40, 2>(a, s) : launch_halo_flags<20, 2>(a, s);

@@ -273,6 +273,8 @@ extern "C" int fp_net_rot_dim(const fp_net *net) { return (net && net->kind == F
 // ---------------------------------------------------------------------------------------------
 // forward schedules
 // ---------------------------------------------------------------------------------------------
+int conv_halo_ksplit(const ConvArgs &a, int num_cu);      // conv_halo.hip
+
 namespace {
 
 struct Conv2dCall {
@@ -289,7 +291,7 @@ struct Conv2dCall {
   int tokens = 400;
 };
 
-int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s) {
+int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scratch = nullptr) {
   ConvArgs a;
   const ConvW &w = *c.cw;
   a.in = c.in;
@@ -317,6 +319,10 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s) {
   a.coff_hi = c.coff_hi;
   a.post_period = c.post_period;
   a.tokens = c.tokens;
+  if (splitk_scratch) {
+    a.ksplit = conv_halo_ksplit(a, ctx->num_cu);
+    a.splitk = a.ksplit > 1 ? splitk_scratch : nullptr;
+  }
   return launch_conv(ctx, a, s);
 }
 
@@ -342,30 +348,36 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
   TAKE(tC, f16, (size_t)N * 400 * 512);
   TAKE(c1, f16, (size_t)N * 400 * 512);
   TAKE(tok, f16, (size_t)N * 400 * 512);
+  // split-K scratch of the 3x3 stride-1 layers for 1 .. 4 hypotheses: 4 shares x the largest fp32 output (256 channels at 40x40)
+  float *sk = nullptr;
+  if (N <= 4) {
+    TAKE(sk_, float, (size_t)4 * N * 1600 * 256 + (size_t)2 * n2 * 1600 * 128);
+    sk = sk_;
+  }
   Conv2dCall c;
   // encodeA / encoderA on cat([A,B],0)
   // (A and B halves of the net tensor may come from different places when the batch is processed in chunks)
-  c = Conv2dCall{xA, N, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{xB, N, 160, 160, &t[0]}; c.out = a0 + (size_t)N * 80 * 80 * 64; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{a0, (int)n2, 80, 80, &t[1]}; c.out = a1; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{a1, (int)n2, 40, 40, &t[2]}; c.out = tA; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{tA, (int)n2, 40, 40, &t[3]}; c.res = a1; c.out = a2; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{a2, (int)n2, 40, 40, &t[4]}; c.out = tA; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{xA, N, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{xB, N, 160, 160, &t[0]}; c.out = a0 + (size_t)N * 80 * 80 * 64; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{a0, (int)n2, 80, 80, &t[1]}; c.out = a1; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{a1, (int)n2, 40, 40, &t[2]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{tA, (int)n2, 40, 40, &t[3]}; c.res = a1; c.out = a2; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{a2, (int)n2, 40, 40, &t[4]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, sk));
   // last conv of encodeA writes the channel-concat cat((a,b),1) directly: image n<N -> channels [0,128), n>=N -> [128,256)
   c = Conv2dCall{tA, (int)n2, 40, 40, &t[5]}; c.res = a2; c.out = ab0; c.out_ld = 256; c.split_m = N * 1600; c.coff_hi = 128;
-  FP_TRY(run_conv(ctx, c, s));
+  FP_TRY(run_conv(ctx, c, s, sk));
   // encodeAB
-  c = Conv2dCall{ab0, N, 40, 40, &t[6]}; c.out = tB; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{tB, N, 40, 40, &t[7]}; c.res = ab0; c.out = ab1; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{ab1, N, 40, 40, &t[8]}; c.out = tB; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{tB, N, 40, 40, &t[9]}; c.res = ab1; c.out = ab0; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{ab0, N, 40, 40, &t[10]}; c.out = c0; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{c0, N, 20, 20, &t[11]}; c.out = tC; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{tC, N, 20, 20, &t[12]}; c.res = c0; c.out = c1; FP_TRY(run_conv(ctx, c, s));
-  c = Conv2dCall{c1, N, 20, 20, &t[13]}; c.out = tC; FP_TRY(run_conv(ctx, c, s));
+  c = Conv2dCall{ab0, N, 40, 40, &t[6]}; c.out = tB; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{tB, N, 40, 40, &t[7]}; c.res = ab0; c.out = ab1; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{ab1, N, 40, 40, &t[8]}; c.out = tB; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{tB, N, 40, 40, &t[9]}; c.res = ab1; c.out = ab0; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{ab0, N, 40, 40, &t[10]}; c.out = c0; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{c0, N, 20, 20, &t[11]}; c.out = tC; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{tC, N, 20, 20, &t[12]}; c.res = c0; c.out = c1; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{c1, N, 20, 20, &t[13]}; c.out = tC; FP_TRY(run_conv(ctx, c, s, sk));
   // reshape(bs,C,-1).permute(0,2,1) is the NHWC tensor itself; pos_embed.pe added in the epilogue
   c = Conv2dCall{tC, N, 20, 20, &t[14]}; c.res = c1; c.out = tok; c.post_add = net->pe; c.post_period = 400;
-  FP_TRY(run_conv(ctx, c, s));
+  FP_TRY(run_conv(ctx, c, s, sk));
   *tokens_out = tok;
   return FP_OK;
 }

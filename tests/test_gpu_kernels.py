@@ -275,6 +275,9 @@ def _pack_conv_weight(w, cin_pad):
   (3, 20, 20, 512, 512, 3, 1, True, True),
   (2, 40, 40, 256, 512, 3, 2, False, True),
   (2, 160, 160, 6, 64, 7, 2, False, True),
+  (1, 20, 20, 512, 512, 3, 1, True, True),          # one hypothesis: 16 quarter tiles -> split-K, 4 shares of 4 chunks + finishing pass
+  (1, 40, 40, 256, 256, 3, 1, False, True),         # split-K, 4 shares of 2 chunks
+  (2, 40, 40, 128, 128, 3, 1, True, False),         # split-K, 2 shares of 2 chunks, no ReLU
   (1, 1, 1000, 512, 1024, 1, 1, False, False),     # a Linear layer (1x1, M=1000 tokens: ragged last tile)
   (1, 1, 130, 512, 64, 1, 1, False, False),
 ])
