@@ -297,7 +297,7 @@ def make_refine_state_dict(seed=0, c_in=6, use_bn=True, rot_out_dim=3, head_gain
 
 
 # ScoreNet tail seeds chosen by tests/golden/gen_fullsize.py (stage 'tail'): largest worst-case top-1 / top-2 margin
-_TAIL_SEED = {1: 5357}
+_TAIL_SEED = {1: 2238}
 
 
 def make_score_state_dict(seed=1, c_in=6, use_bn=True, tail_seed=None, tail_only=False):
