@@ -543,7 +543,13 @@ int launch_token_mean(const f16 *x, int Bn, int T, float *out, hipStream_t s) {
   return FP_OK;
 }
 
-// y[m][n] = sum_k x[m][k] w[n][k] + b[n], fp32, one wave per output element group (tiny matrices:
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// y[m][n] = sum_k x[m][k] w[n][k] + b[n], fp32 in / out, one wave per output element group (tiny matrices:
 // the per-object score tail, 0.66 GFLOP per 252 hypotheses).
 __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                            const float *__restrict__ bias, int M, int K, int N,
@@ -552,14 +558,16 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= N) return;
   const float *xr = x + (size_t)m * K, *wr = w + (size_t)n * K;
-  float s = 0.f;
+  // float64 accumulation: these layers form the cross-hypothesis score tail, whose logits differ between hypotheses by 1e-4 ..
+  // 1e-3 on top of O(1) common parts - fp32 summation noise (4e-6) would be a visible part of that; the work is negligible
+  double s = 0.0;
   for (int k = lane * 4; k < K; k += 256) {
     const float4 a = *reinterpret_cast<const float4 *>(xr + k);
     const float4 c = *reinterpret_cast<const float4 *>(wr + k);
-    s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+    s += (double)a.x * c.x + (double)a.y * c.y + (double)a.z * c.z + (double)a.w * c.w;
   }
-  s = wave_sum(s);
-  if (lane == 0) out[(size_t)m * N + n] = s + (bias ? bias[n] : 0.f);
+  s = wave_sum_d(s);
+  if (lane == 0) out[(size_t)m * N + n] = (float)(s + (bias ? (double)bias[n] : 0.0));
 }
 
 int launch_small_linear(const float *x, const float *w, const float *b, int M, int K, int N, float *out, hipStream_t s) {
@@ -572,42 +580,44 @@ int launch_small_linear(const float *x, const float *w, const float *b, int M, i
 
 // Cross-hypothesis self-attention (score_network.py:83): qkv (groups*L, 1536) fp32 -> out (groups*L, 512).
 // One workgroup per (query, group); 4 waves = 4 heads; scores held in LDS (L <= 4096).
-#define CA_MAXL 4096
+#define CA_MAXL 2048
 __global__ __launch_bounds__(256) void cross_attention_kernel(const float *__restrict__ qkv, int L, float *__restrict__ out) {
-  __shared__ float sc[4][CA_MAXL];
+  // float64 scores / softmax / weighted sum (see small_linear_kernel): with the q/k gain of the seeded scorer the scores are
+  // O(100) with hypothesis-specific parts of O(1); in fp32 their rounding alone moves the logits by several 1e-6
+  __shared__ double sc[4][CA_MAXL];
   const int i = blockIdx.x, grp = blockIdx.y, hd = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float *base = qkv + (size_t)grp * L * 1536;
   const float *qr = base + (size_t)i * 1536 + hd * 128;
-  const float q0 = qr[lane * 2], q1 = qr[lane * 2 + 1];
-  const float scale = 0.08838834764831845f;
-  float mx = -3.0e38f;
+  const double q0 = qr[lane * 2], q1 = qr[lane * 2 + 1];
+  const double scale = 0.08838834764831845;
+  double mx = -1.0e300;
   for (int j = 0; j < L; ++j) {
     const float *kr = base + (size_t)j * 1536 + 512 + hd * 128;
-    float s = wave_sum(q0 * kr[lane * 2] + q1 * kr[lane * 2 + 1]) * scale;
+    const double s = wave_sum_d(q0 * (double)kr[lane * 2] + q1 * (double)kr[lane * 2 + 1]) * scale;
     if (lane == 0) sc[hd][j] = s;
-    mx = fmaxf(mx, s);
+    mx = fmax(mx, s);
   }
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  float sum = 0.f;
+  double sum = 0.0;
   for (int j = lane; j < L; j += 64) {
-    float e = __expf(sc[hd][j] - mx);
+    const double e = exp(sc[hd][j] - mx);
     sc[hd][j] = e;
     sum += e;
   }
-  sum = wave_sum(sum);
+  sum = wave_sum_d(sum);
   __syncthreads();
-  float o0 = 0.f, o1 = 0.f;
+  double o0 = 0.0, o1 = 0.0;
   for (int j = 0; j < L; ++j) {
     const float *vr = base + (size_t)j * 1536 + 1024 + hd * 128;
-    const float pj = sc[hd][j];
-    o0 += pj * vr[lane * 2];
-    o1 += pj * vr[lane * 2 + 1];
+    const double pj = sc[hd][j];
+    o0 += pj * (double)vr[lane * 2];
+    o1 += pj * (double)vr[lane * 2 + 1];
   }
-  const float inv = 1.f / sum;
+  const double inv = 1.0 / sum;
   float *orow = out + ((size_t)grp * L + i) * 512 + hd * 128;
-  orow[lane * 2] = o0 * inv;
-  orow[lane * 2 + 1] = o1 * inv;
+  orow[lane * 2] = (float)(o0 * inv);
+  orow[lane * 2 + 1] = (float)(o1 * inv);
 }
 
 int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s) {

@@ -74,3 +74,10 @@ def net_inputs(seed, n):
       imgs[i, :3], imgs[i, 3:] = rgb, xyz
     sides.append(torch.from_numpy(imgs))
   return sides
+
+
+def nearest_pose_error(got, want):
+  """max over `got` poses of the distance to the nearest `want` pose (max-abs over the 16 entries): compares two pose SETS whose
+  order (a ranking by nearly tied scores) may differ."""
+  got, want = np.asarray(got, dtype=np.float64).reshape(-1, 16), np.asarray(want, dtype=np.float64).reshape(-1, 16)
+  return float(np.abs(got[:, None] - want[None]).max(-1).min(1).max())
