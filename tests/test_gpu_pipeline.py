@@ -189,10 +189,12 @@ def test_register_matches_oracle_config0(estimators):
       print(f'iteration={iteration}: max |pose_gpu - pose_oracle| over 32 hypotheses = {perr:.2e}')
       assert perr < 1e-3
       # scoring on the ORACLE's refined poses (isolates the scorer from refinement noise)
-      sg, _ = est.scorer.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=sc['rgb'], depth=depth, K=sc['K'],
-                                 ob_in_cams=po.numpy(), mesh_diameter=est.diameter)
-      so = OP.score_predict(orc.score_cfg, orc.score_sd, sc['rgb'], depth, sc['K'], po.numpy(), sc['mt'], sc['diameter'], chunk=16)
-      sg, so = sg.cpu().numpy(), so.numpy()
+      # raw logits on both sides: the reference's `+ 100` (predict_score.py:209) quantises float32 scores to 7.6e-6
+      fg = est.scorer.extract_features(sc['rgb'], depth, sc['K'], po.numpy(), mesh_tensors=est.mesh_tensors, mesh_diameter=est.diameter)
+      sg = est.scorer.score_tail(fg, L=len(fg))[0].reshape(-1).cpu().numpy()
+      tr = []
+      OP.score_predict(orc.score_cfg, orc.score_sd, sc['rgb'], depth, sc['K'], po.numpy(), sc['mt'], sc['diameter'], chunk=16, trace=tr)
+      so = tr[0]['logits'].numpy()
       # a common shift of all logits cannot change the ranking: split the error into common + differential
       common = float((sg - so).mean())
       noise, spread = float(np.abs((sg - sg.mean()) - (so - so.mean())).max()), float(so.std())
@@ -399,8 +401,8 @@ def test_register_textured_symmetric_object():
   pose_o = orc.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=1, chunk=12)
   so, sg = np.asarray(orc.scores), est.scores.cpu().numpy()           # both sorted, best first
   np.testing.assert_allclose(sg, so, atol=3e-3)
-  noise = float(np.abs((sg - sg.mean()) - (so - so.mean())).max())
-  assert so[0] - so[1] >= 20 * noise, f'margin {so[0] - so[1]:.2e} vs logit noise {noise:.2e}'      # case tex24 of tests/cases.py
+  # (scores = logits + 100 in float32 on both sides: quantised to 7.6e-6; the raw logits, the margin and the measured noise
+  # of this very case are asserted in tests/test_gpu_golden_fullsize.py, case tex24)
   assert int(est.best_id) == int(orc.best_id)
   np.testing.assert_allclose(pose_g, pose_o, atol=1e-3)
   assert util.nearest_pose_error(est.poses.cpu().numpy(), np.asarray(orc.poses)) < 1e-3
