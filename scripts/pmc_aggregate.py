@@ -1,9 +1,11 @@
-"""gpurun_out/pmc_traffic/{fetch,write}/*_counter_collection.csv  ->  profiles/r01_pmc_hbm_traffic.csv (+ r01_halo_traffic.json).
+"""gpurun_out/pmc_traffic/{fetch,write}/*_counter_collection.csv  ->  profiles/<ROUND>_pmc_hbm_traffic.csv, <ROUND>_halo_traffic.json and
+<ROUND>_head_chain_traffic.json (ROUND from the environment, default r02).
 
 FETCH_SIZE / WRITE_SIZE are reported in KB.  On gfx950 FETCH_SIZE counts a 128-byte request of a 16-B/lane stream as 64 B:
 it is doubled here (MI355X_MICROARCH.md); WRITE_SIZE is taken as is.  Infinity-Cache hits are part of FETCH_SIZE, so the sum
 is fabric (L2-miss) traffic - an upper bound on HBM bytes."""
 import collections, csv, glob, json, os
+ROUND = os.environ.get('ROUND', 'r02')
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -16,6 +18,36 @@ def load(kind, counter):
   return agg
 
 
+HEAD_KERNELS = ('tok_gemm', 'attention_kernel', 'mean_head', 'vt_pad_zero', 'layernorm', 'ln_partial', 'token_mean', 'conv_igemm2_kernelILi128ELi1', 'conv_igemm2_kernelILi64ELi1')
+
+
+def chain_bytes(rows):
+  """fabric bytes per bench step of the transformer-head kernels: rows = (kernel, grid, launches, raw, fetch MB, write MB)"""
+  steps = sum(int(r[2]) for r in rows if 'render_kernel<1' in r[0]) / 6.0        # 6 fused renders per bench step
+  tot = collections.OrderedDict()
+  for r in rows:
+    if any(k in r[0] for k in HEAD_KERNELS):
+      key = r[0].split('<')[0].replace('void ', '')[:40]
+      tot[key] = tot.get(key, 0.0) + (float(r[4]) + float(r[5])) * int(r[2]) * 1e6 / steps
+  return tot
+
+
+def head_chain(rows):
+  """Bytes moved by the head chain (in-projections, attention, out-projection, LayerNorms, FFN, token mean) in one bench step of
+  11 head passes (2 heads x 5 refine iterations + ScoreNet's attention), this round against the committed round-1 profile."""
+  now = chain_bytes(rows)
+  before = {}
+  old = os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.csv')
+  if os.path.exists(old):
+    before = chain_bytes([(r['kernel'], r['grid_threads'], r['launches'], r['FETCH_SIZE_KB_raw_mean'], r['fetch_MB_corrected_x2'], r['WRITE_SIZE_MB_mean'])
+                          for r in csv.DictReader(open(old))])
+  js = {'unit': 'bytes per bench step (fetch x2-corrected + write), 11 head passes', 'this_round': now, 'this_round_total': sum(now.values()),
+        'round1': before, 'round1_total': sum(before.values()),
+        'ratio': (sum(now.values()) / sum(before.values())) if before else None}
+  json.dump(js, open(os.path.join(REPO, 'profiles', f'{ROUND}_head_chain_traffic.json'), 'w'), indent=1)
+  print(json.dumps(js, indent=1))
+
+
 def main():
   fetch, write = load('fetch', 'FETCH_SIZE'), load('write', 'WRITE_SIZE')
   rows = []
@@ -23,7 +55,7 @@ def main():
     name, grid = key
     fv, wv = fetch[key], write.get(key, [0.0])
     rows.append((name.split('(')[0][:90], grid, len(fv), sum(fv) / len(fv), 2 * sum(fv) / len(fv) / 1e3, sum(wv) / len(wv) / 1e3))
-  out = os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.csv')
+  out = os.path.join(REPO, 'profiles', f'{ROUND}_pmc_hbm_traffic.csv')
   with open(out, 'w') as f:
     f.write('kernel,grid_threads,launches,FETCH_SIZE_KB_raw_mean,fetch_MB_corrected_x2,WRITE_SIZE_MB_mean\n')
     for r in rows:
@@ -41,10 +73,11 @@ def main():
   js = {'per': 'launch (mean over the stride-1 3x3 convolutions of one bench step, N=252)', 'unit': 'bytes', 'fetch': fe, 'write': wr,
         'total': fe + wr, 'algorithmic': algo, 'launches_profiled': n,
         'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (scripts/pmc_traffic.sh, '
-                  'profiles/r01_pmc_hbm_traffic.csv); FETCH_SIZE doubled (gfx950 counts 128-B requests of 16-B/lane streams as 64 B), '
+                  'profiles/' + ROUND + '_pmc_hbm_traffic.csv); FETCH_SIZE doubled (gfx950 counts 128-B requests of 16-B/lane streams as 64 B), '
                   'WRITE_SIZE as is; Infinity-Cache hits are included in FETCH_SIZE, so this is fabric (L2-miss) traffic, an upper '
                   'bound on HBM bytes'}
-  json.dump(js, open(os.path.join(REPO, 'profiles', 'r01_halo_traffic.json'), 'w'), indent=1)
+  json.dump(js, open(os.path.join(REPO, 'profiles', f'{ROUND}_halo_traffic.json'), 'w'), indent=1)
+  head_chain(rows)
   print(open(out).read()[:1500])
   print(json.dumps(js, indent=1)[:600])
 
