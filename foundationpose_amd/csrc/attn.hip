@@ -570,10 +570,43 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
   if (lane == 0) out[(size_t)m * N + n] = (float)(s + (bias ? (double)bias[n] : 0.0));
 }
 
-int launch_small_linear(const float *x, const float *w, const float *b, int M, int K, int N, float *out, hipStream_t s) {
-  FP_REQUIRE(K % 4 == 0, "small_linear: K=%d must be a multiple of 4", K);
+// The same for N >= 64 columns: one LANE per output column (weights transposed (K, N): lanes read consecutive columns of a row,
+// coalesced), 4 rows of x per workgroup staged in LDS and read as broadcasts - 512 float64 FMAs per output and NO cross-lane
+// reduction (the wave-per-output form spends most of its instructions on 64-lane double reductions, in ~10^5 workgroups).
+#define SLT_ROWS 4
+__global__ __launch_bounds__(256) void small_linear_t_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                             const float *__restrict__ bias, int M, int K, int N, float *__restrict__ out) {
+  __shared__ float xs[SLT_ROWS][1024];
+  const int m0 = blockIdx.y * SLT_ROWS, n = blockIdx.x * 256 + threadIdx.x;
+  for (int i = threadIdx.x; i < SLT_ROWS * K; i += 256) {
+    const int r = i / K, k = i - r * K;
+    xs[r][k] = x[(size_t)min(m0 + r, M - 1) * K + k];
+  }
+  __syncthreads();
+  if (n >= N) return;
+  double acc[SLT_ROWS];
+#pragma unroll
+  for (int r = 0; r < SLT_ROWS; ++r) acc[r] = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    float wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wv[u] = wt[(size_t)(k0 + u) * N + n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int r = 0; r < SLT_ROWS; ++r) acc[r] += (double)xs[r][k0 + u] * (double)wv[u];
+  }
+  const double b = bias ? (double)bias[n] : 0.0;
+#pragma unroll
+  for (int r = 0; r < SLT_ROWS; ++r)
+    if (m0 + r < M) out[(size_t)(m0 + r) * N + n] = (float)(acc[r] + b);
+}
+
+int launch_small_linear(const float *x, const float *w, const float *wt, const float *b, int M, int K, int N, float *out, hipStream_t s) {
+  FP_REQUIRE(K % 8 == 0 && K <= 1024, "small_linear: K=%d must be a multiple of 8, <= 1024", K);
   if (M == 0 || N == 0) return FP_OK;
-  hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4, M), dim3(256), 0, s, x, w, b, M, K, N, out);
+  if (wt && N >= 64) hipLaunchKernelGGL(small_linear_t_kernel, dim3((N + 255) / 256, (M + SLT_ROWS - 1) / SLT_ROWS), dim3(256), 0, s, x, wt, b, M, K, N, out);
+  else hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4, M), dim3(256), 0, s, x, w, b, M, K, N, out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
@@ -591,11 +624,18 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const float *__res
   const double q0 = qr[lane * 2], q1 = qr[lane * 2 + 1];
   const double scale = 0.08838834764831845;
   double mx = -1.0e300;
-  for (int j = 0; j < L; ++j) {
-    const float *kr = base + (size_t)j * 1536 + 512 + hd * 128;
-    const double s = wave_sum_d(q0 * (double)kr[lane * 2] + q1 * (double)kr[lane * 2 + 1]) * scale;
-    if (lane == 0) sc[hd][j] = s;
-    mx = fmax(mx, s);
+  for (int j0 = 0; j0 < L; j0 += 8) {               // eight key rows in flight (a rolled loop waits for each row's load in turn)
+    float2 kv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) kv[u] = *reinterpret_cast<const float2 *>(base + (size_t)min(j0 + u, L - 1) * 1536 + 512 + hd * 128 + lane * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double s = wave_sum_d(q0 * (double)kv[u].x + q1 * (double)kv[u].y) * scale;
+      if (j0 + u < L) {
+        if (lane == 0) sc[hd][j0 + u] = s;
+        mx = fmax(mx, s);
+      }
+    }
   }
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
@@ -608,11 +648,17 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const float *__res
   sum = wave_sum_d(sum);
   __syncthreads();
   double o0 = 0.0, o1 = 0.0;
-  for (int j = 0; j < L; ++j) {
-    const float *vr = base + (size_t)j * 1536 + 1024 + hd * 128;
-    const double pj = sc[hd][j];
-    o0 += pj * (double)vr[lane * 2];
-    o1 += pj * (double)vr[lane * 2 + 1];
+  for (int j0 = 0; j0 < L; j0 += 8) {
+    float2 vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const float2 *>(base + (size_t)min(j0 + u, L - 1) * 1536 + 1024 + hd * 128 + lane * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + u < L) {
+        const double pj = sc[hd][j0 + u];
+        o0 += pj * (double)vv[u].x;
+        o1 += pj * (double)vv[u].y;
+      }
   }
   const double inv = 1.0 / sum;
   float *orow = out + ((size_t)grp * L + i) * 512 + hd * 128;

@@ -244,7 +244,7 @@ int launch_ln_mean_head_h(const f16 *x, const float *g, const float *b, int Bn, 
 int launch_ln_mean_head(const float *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
                         int out_dim, float *out, float *scratch /* Bn*8*512 */, hipStream_t s);
 int launch_token_mean(const f16 *x, int Bn, int T, float *out, hipStream_t s);
-int launch_small_linear(const float *x, const float *w, const float *b, int M, int K, int N, float *out, hipStream_t s);
+int launch_small_linear(const float *x, const float *w, const float *wt, const float *b, int M, int K, int N, float *out, hipStream_t s);
 int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s);
 int launch_argmax(const float *logits, int groups, int L, int32_t *out, hipStream_t s);
 int launch_pose_update(const float *poseA, const float *trans, const float *rot, int N, int rot_dim, int trans_tanh,

@@ -435,6 +435,9 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / NPW, wn = wave % NPW;
   const int lr = lane & 31, lh = lane >> 5;
+  // static priority for the second-dispatched half of the workgroup (waves 4-7 are the arbitration loser of each SIMD pair at
+  // equal priority): measured A/B in one session, 39.55 / 39.33 -> 38.99 / 38.92 ms per step, 1139 / 1145 -> 1153 / 1157 TF/s
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by band row 0
   const int total_rows = p.Nimg * H;
   // input-channel chunks [cbeg, nchunk) of this workgroup: all of them, or (SPLIT) share ks of p.ksplit equal shares

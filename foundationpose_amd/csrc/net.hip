@@ -26,7 +26,7 @@ struct HeadW {  // one nn.TransformerEncoderLayer + Linear
 };
 
 struct LinF32 {
-  float *w = nullptr, *b = nullptr;
+  float *w = nullptr, *b = nullptr, *wt = nullptr;      // w: (N, K) row-major; wt: its transpose (K, N) for the column-per-lane kernel
   int N = 0, K = 0;
 };
 
@@ -179,7 +179,11 @@ int make_linf32(fp_net *net, const SD &sd, const std::string &wkey, const std::s
   out->K = K;
   FP_TRY(make_vec(net, sd, wkey, N * K, &out->w));
   FP_TRY(make_vec(net, sd, bkey, N, &out->b));
-  return FP_OK;
+  const fp_tensor *t = sd.get(wkey);
+  std::vector<float> tr((size_t)N * K);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) tr[(size_t)k * N + n] = t->data[(size_t)n * K + k];
+  return upload(net, tr, &out->wt);
 }
 
 int make_trunk(fp_net *net, const SD &sd, const std::string &eA, const std::string &eAB, bool bn) {
@@ -568,7 +572,7 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
     FP_TRY(launch_attention(ctx, qk, vt, N, 400, att, s));
     // mean over tokens commutes with out_proj (score_network.py:73-74)
     FP_TRY(launch_token_mean(att, N, 400, mean, s));
-    FP_TRY(launch_small_linear(mean, net->att_out.w, net->att_out.b, N, 512, 512, d_feats + (size_t)s0 * 512, s));
+    FP_TRY(launch_small_linear(mean, net->att_out.w, net->att_out.wt, net->att_out.b, N, 512, 512, d_feats + (size_t)s0 * 512, s));
     return FP_OK;
   };
   int rc = FP_OK;
@@ -593,10 +597,10 @@ extern "C" int fp_score_tail(fp_ctx *ctx, const fp_net *net, const float *d_feat
     TAKE(qkv, float, (size_t)M * 1536);
     TAKE(ca, float, (size_t)M * 512);
     TAKE(co, float, (size_t)M * 512);
-    FP_TRY(launch_small_linear(d_feats, net->cross_in.w, net->cross_in.b, M, 512, 1536, qkv, s));
+    FP_TRY(launch_small_linear(d_feats, net->cross_in.w, net->cross_in.wt, net->cross_in.b, M, 512, 1536, qkv, s));
     FP_TRY(launch_cross_attention(qkv, groups, L, ca, s));
-    FP_TRY(launch_small_linear(ca, net->cross_out.w, net->cross_out.b, M, 512, 512, co, s));
-    FP_TRY(launch_small_linear(co, net->lin.w, net->lin.b, M, 512, 1, d_logits, s));
+    FP_TRY(launch_small_linear(ca, net->cross_out.w, net->cross_out.wt, net->cross_out.b, M, 512, 512, co, s));
+    FP_TRY(launch_small_linear(co, net->lin.w, net->lin.wt, net->lin.b, M, 512, 1, d_logits, s));
     if (d_argmax) FP_TRY(launch_argmax(d_logits, groups, L, d_argmax, s));
     return FP_OK;
   };
