@@ -13,6 +13,7 @@
 //   shading, and either fp32 channels-last maps (API parity with nvdiffrast_render) or the fused
 //   network-ready fp16 NHWC8 tensor (rgb, (xyz-t)*2/diam with invalid masking; h5_dataset.py:92-99),
 //   written as one coalesced 16-byte store per pixel.
+// Triangles that straddle the camera plane are rasterised in homogeneous coordinates (below).
 // The arithmetic is mirrored 1:1 by oracle/raster_c.c.
 #include "common.h"
 
@@ -51,6 +52,67 @@ __device__ __forceinline__ Vtx xform_vertex(const float *__restrict__ pos, int v
     }
   }
   return o;
+}
+
+// ---- triangles that straddle the camera plane (a vertex with w <= 0 or projected out of range, another in front) ----------
+// nvdiffrast clips such triangles against the frustum; dropping them (round 1) leaves holes in an object that reaches behind
+// the camera.  They are rasterised in 2-D homogeneous coordinates instead (no clipping, no new vertices): with the
+// pixel-homogeneous vertices v_k = (cx hw + cw hw, cy hh + cw hh, cw) the barycentric weights of the surface point seen at
+// pixel centre p = (i + .5, j + .5, 1) are b_k = l_k / (l_0 + l_1 + l_2), l_k = sign(D) n_k . p, n_0 = v_1 x v_2 (cyclic),
+// D = v_0 . n_0; the point is on the triangle and in front of the camera iff every l_k > 0.  z/w = sum l_k cz_k / sum l_k cw_k
+// (the same projective depth the screen-affine interpolation gives) must lie in [-1, 1]: that IS the near / far clip, per
+// pixel.  All float32, fixed operation order, no contraction - mirrored by oracle/raster_c.c.
+struct ClipTri {
+  float n[3][3];     // sign-normalised edge normals
+  float cz[3], cw[3];
+  bool valid;
+};
+
+__device__ __forceinline__ void clip_coords(const float *__restrict__ pos, int v, const float *M, float *c) {
+  const float px = pos[v * 3], py = pos[v * 3 + 1], pz = pos[v * 3 + 2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = fmaf(M[r * 4 + 0], px, fmaf(M[r * 4 + 1], py, fmaf(M[r * 4 + 2], pz, M[r * 4 + 3])));
+}
+
+__device__ __forceinline__ ClipTri clip_setup(const float c[3][4], float hw, float hh) {
+  ClipTri T;
+  float v[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    v[k][0] = __fadd_rn(__fmul_rn(c[k][0], hw), __fmul_rn(c[k][3], hw));
+    v[k][1] = __fadd_rn(__fmul_rn(c[k][1], hh), __fmul_rn(c[k][3], hh));
+    v[k][2] = c[k][3];
+    T.cz[k] = c[k][2];
+    T.cw[k] = c[k][3];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float *a = v[(k + 1) % 3], *b = v[(k + 2) % 3];
+    T.n[k][0] = __fsub_rn(__fmul_rn(a[1], b[2]), __fmul_rn(a[2], b[1]));
+    T.n[k][1] = __fsub_rn(__fmul_rn(a[2], b[0]), __fmul_rn(a[0], b[2]));
+    T.n[k][2] = __fsub_rn(__fmul_rn(a[0], b[1]), __fmul_rn(a[1], b[0]));
+  }
+  const float D = __fadd_rn(__fadd_rn(__fmul_rn(v[0][0], T.n[0][0]), __fmul_rn(v[0][1], T.n[0][1])), __fmul_rn(v[0][2], T.n[0][2]));
+  T.valid = D != 0.f && isfinite(D);
+  const float sg = D > 0.f ? 1.f : -1.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int e = 0; e < 3; ++e) T.n[k][e] = __fmul_rn(T.n[k][e], sg);
+  return T;
+}
+
+// weights l_k at pixel (i, j) and z/w; false if the pixel does not see the triangle
+__device__ __forceinline__ bool clip_eval(const ClipTri &T, int i, int j, float *l, float *zp) {
+  const float Px = (float)i + 0.5f, Py = (float)j + 0.5f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) l[k] = __fadd_rn(__fadd_rn(__fmul_rn(T.n[k][0], Px), __fmul_rn(T.n[k][1], Py)), T.n[k][2]);
+  if (!(l[0] > 0.f && l[1] > 0.f && l[2] > 0.f)) return false;
+  const float num = __fadd_rn(__fadd_rn(__fmul_rn(l[0], T.cz[0]), __fmul_rn(l[1], T.cz[1])), __fmul_rn(l[2], T.cz[2]));
+  const float den = __fadd_rn(__fadd_rn(__fmul_rn(l[0], T.cw[0]), __fmul_rn(l[1], T.cw[1])), __fmul_rn(l[2], T.cw[2]));
+  if (!(den > 0.f)) return false;
+  *zp = __fdiv_rn(num, den);
+  return *zp >= -1.f && *zp <= 1.f;
 }
 
 // clip matrix of hypothesis b in float64, rounded once (oracle/render.py: clip_matrices; src/Utils.py:155-181); one thread
@@ -144,8 +206,23 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   // ---- pass 1: stream triangles, resolve visibility in LDS.  Four triangles per thread are in flight at a time: their index
   // and vertex loads (two dependent memory round trips) are issued together - at 1 .. 64 hypotheses a workgroup is alone on
   // its CU and the loop is latency-bound (tracking: 86 -> see DESIGN.md us per render); coverage and keys do not depend on order.
-  auto raster_tri = [&](const int t, const Vtx &v0, const Vtx &v1, const Vtx &v2) __attribute__((always_inline)) {
-    if (!(v0.ok && v1.ok && v2.ok)) return;
+  auto raster_tri = [&](const int t, const int *fi3, const Vtx &v0, const Vtx &v1, const Vtx &v2) __attribute__((always_inline)) {
+    if (!(v0.ok && v1.ok && v2.ok)) {
+      if (!(v0.w > 0.f || v1.w > 0.f || v2.w > 0.f)) return;      // entirely behind the camera
+      float c[3][4];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) clip_coords(m.pos, fi3[k], M, c[k]);
+      const ClipTri T = clip_setup(c, hw, hh);
+      if (!T.valid) return;
+      for (int j = row0; j < row1; ++j)
+        for (int i = 0; i < Wo; ++i) {
+          float l[3], zp;
+          if (!clip_eval(T, i, j, l, &zp)) continue;
+          const unsigned long long key = ((unsigned long long)ordered_key(zp) << 32) | (unsigned)t;
+          atomicMin(&zbuf[(j - row0) * Wo + i], key);
+        }
+      return;
+    }
     // Triangles whose snapped coordinates stay within +-1024 px (all but the ones far outside the crop) take the same
     // integer edge functions in 32-bit arithmetic: |X|,|Y| < 2^14 -> differences < 2^15, products < 2^30, sums < 2^31.
     // The values are the same integers as in the 64-bit path, so coverage, barycentrics and depth keys are bit-identical.
@@ -239,7 +316,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
       for (int k = 0; k < 3; ++k) fv[u][k] = vertex(fi[u][k]);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (t0 + u * RB_THREADS < m.F) raster_tri(t0 + u * RB_THREADS, fv[u][0], fv[u][1], fv[u][2]);
+      if (t0 + u * RB_THREADS < m.F) raster_tri(t0 + u * RB_THREADS, fi[u], fv[u][0], fv[u][1], fv[u][2]);
   }
   __syncthreads();
 
@@ -258,8 +335,21 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
       int i0 = m.faces[t * 3], i1 = m.faces[t * 3 + 1], i2 = m.faces[t * 3 + 2];
       Vtx v0 = vertex(i0), v1 = vertex(i1), v2 = vertex(i2);
       float fa, b0, b1, b2;
-      const int amax = max(max(max(abs(v0.X), abs(v0.Y)), max(abs(v1.X), abs(v1.Y))), max(abs(v2.X), abs(v2.Y)));
-      if (amax < 16384) {                         // the same integers in 32-bit arithmetic (see pass 1)
+      float u, v, w2;
+      const bool clipped = !(v0.ok && v1.ok && v2.ok);
+      const int amax = clipped ? 0 : max(max(max(abs(v0.X), abs(v0.Y)), max(abs(v1.X), abs(v1.Y))), max(abs(v2.X), abs(v2.Y)));
+      if (clipped) {                              // straddles the camera plane: weights from the homogeneous edge functions
+        float c[3][4];
+        const int id3[3] = {i0, i1, i2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) clip_coords(m.pos, id3[k], M, c[k]);
+        const ClipTri T = clip_setup(c, hw, hh);
+        float l[3], zp;
+        (void)clip_eval(T, i, j, l, &zp);
+        const float ls = __fadd_rn(__fadd_rn(l[0], l[1]), l[2]);
+        u = __fdiv_rn(l[0], ls), v = __fdiv_rn(l[1], ls), w2 = (1.f - u) - v;
+        fa = b0 = b1 = b2 = 0.f;
+      } else if (amax < 16384) {                  // the same integers in 32-bit arithmetic (see pass 1)
         const int X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
         int area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
         const int sg = area > 0 ? 1 : -1;
@@ -282,9 +372,11 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
         fa = (float)area;
         b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
       }
-      float q0 = b0 / v0.w, q1 = b1 / v1.w, q2 = b2 / v2.w;
-      float qs = (q0 + q1) + q2;
-      float u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
+      if (!clipped) {
+        float q0 = b0 / v0.w, q1 = b1 / v1.w, q2 = b2 / v2.w;
+        float qs = (q0 + q1) + q2;
+        u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
+      }
       const int idx[3] = {i0, i1, i2};
       float pc[3][3], nc[3][3], dv[3];
 #pragma unroll

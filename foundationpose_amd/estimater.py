@@ -10,7 +10,6 @@ the HIP library; with `dist_group` set the hypotheses are sharded over the ranks
 """
 import logging
 import os
-import uuid
 
 import numpy as np
 import torch
@@ -74,10 +73,9 @@ class FoundationPose:
     self.max_xyz, self.min_xyz = pts.max(axis=0), pts.min(axis=0)
     self.pts = torch.as_tensor(pts, dtype=torch.float32, device='cuda')
     self.normals = None if nrm is None else torch.as_tensor(nrm, dtype=torch.float32, device='cuda')
+    # (the reference also writes the centred mesh to /tmp/<uuid>.obj here, src/estimater.py:69-70; nothing on the path reads that
+    # file back, so none is written: no file is left behind per object)
     self.mesh_path = None
-    if hasattr(centred, 'export'):
-      self.mesh_path = f'/tmp/{uuid.uuid4()}.obj'
-      centred.export(self.mesh_path)
     self.mesh_tensors = U.make_mesh_tensors(centred)
     sym = torch.eye(4)[None] if symmetry_tfs is None else torch.as_tensor(symmetry_tfs)
     self.symmetry_tfs = sym.to(device='cuda', dtype=torch.float)

@@ -7,7 +7,8 @@
  *   shading (:199-212), mask (:215), row flips (:216-218)
  * nvdiffrast itself is not in the reference checkout nor in this image: PARITY UNPINNED.  The
  * rules fixed here (and mirrored 1:1 by foundationpose_amd/csrc/raster.hip) are:
- *   - clip = M * (p,1) evaluated as an fmaf chain; w<=0 or |screen|>1e6 culls the triangle
+ *   - clip = M * (p,1) evaluated as an fmaf chain; a triangle with a vertex at w<=0 or |screen|>1e6 (it straddles the camera
+ *     plane) is rasterised in 2-D homogeneous coordinates instead of being clipped: clip_setup / clip_eval below
  *   - screen coordinates snapped to 1/16 pixel (rintf), integer edge functions, top-left rule
  *   - both windings are rasterised (nvdiffrast does not cull back faces)
  *   - depth = screen-affine interpolation of z/w; -1<=z/w<=1; nearest wins, ties -> lower face id
@@ -53,6 +54,46 @@ static void tex_fetch(const oracle_mesh *m, float u, float v, float *rgb) {
   }
 }
 
+/* Homogeneous rasterisation of a triangle that straddles the camera plane (nvdiffrast clips it; see raster.hip): pixel-homogeneous
+ * vertices v_k = (cx hw + cw hw, cy hh + cw hh, cw), edge normals n_0 = v_1 x v_2 (cyclic) times sign(D), D = v_0 . n_0; weights
+ * l_k = n_k . (i+.5, j+.5, 1); the pixel sees the triangle iff all l_k > 0; z/w = sum l_k cz_k / sum l_k cw_k in [-1,1]. */
+typedef struct { float n[3][3], cz[3], cw[3]; int valid; } clip_tri;
+
+static clip_tri clip_setup(const float *c0, const float *c1, const float *c2, float hw, float hh) {
+  clip_tri T;
+  const float *c[3] = {c0, c1, c2};
+  float v[3][3];
+  for (int k = 0; k < 3; ++k) {
+    v[k][0] = c[k][0] * hw + c[k][3] * hw;
+    v[k][1] = c[k][1] * hh + c[k][3] * hh;
+    v[k][2] = c[k][3];
+    T.cz[k] = c[k][2];
+    T.cw[k] = c[k][3];
+  }
+  for (int k = 0; k < 3; ++k) {
+    const float *a = v[(k + 1) % 3], *b = v[(k + 2) % 3];
+    T.n[k][0] = a[1] * b[2] - a[2] * b[1];
+    T.n[k][1] = a[2] * b[0] - a[0] * b[2];
+    T.n[k][2] = a[0] * b[1] - a[1] * b[0];
+  }
+  float D = (v[0][0] * T.n[0][0] + v[0][1] * T.n[0][1]) + v[0][2] * T.n[0][2];
+  T.valid = D != 0.f && isfinite(D);
+  float sg = D > 0.f ? 1.f : -1.f;
+  for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) T.n[k][e] = T.n[k][e] * sg;
+  return T;
+}
+
+static int clip_eval(const clip_tri *T, int i, int j, float *l, float *zp) {
+  float Px = (float)i + 0.5f, Py = (float)j + 0.5f;
+  for (int k = 0; k < 3; ++k) l[k] = (T->n[k][0] * Px + T->n[k][1] * Py) + T->n[k][2];
+  if (!(l[0] > 0.f && l[1] > 0.f && l[2] > 0.f)) return 0;
+  float num = (l[0] * T->cz[0] + l[1] * T->cz[1]) + l[2] * T->cz[2];
+  float den = (l[0] * T->cw[0] + l[1] * T->cw[1]) + l[2] * T->cw[2];
+  if (!(den > 0.f)) return 0;
+  *zp = num / den;
+  return *zp >= -1.f && *zp <= 1.f;
+}
+
 /* M: B*16 float (row-major clip matrix incl. bbox window transform), pose: B*16 float (ob_in_cam).
  * outputs (each may be NULL): color B*Ho*Wo*3, depth B*Ho*Wo, normal B*Ho*Wo*3, xyz B*Ho*Wo*3,
  * rast B*Ho*Wo*4 = (u, v, z/w, face_id+1) already flipped top-down. */
@@ -64,6 +105,7 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
 #pragma omp parallel for schedule(dynamic, 1)
   for (int b = 0; b < B; ++b) {
     const float *M = Mclip + (size_t)b * 16, *P = pose + (size_t)b * 16;
+    float *clipc = (float *)malloc(sizeof(float) * V * 4);      /* clip coordinates */
     float *clipw = (float *)malloc(sizeof(float) * V);          /* w */
     float *zn = (float *)malloc(sizeof(float) * V);             /* z/w */
     int32_t *fx = (int32_t *)malloc(sizeof(int32_t) * V * 2);   /* fixed-point screen */
@@ -72,7 +114,7 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
     float *nc = (float *)malloc(sizeof(float) * V * 3);         /* camera-space normal */
     float *dv = (float *)malloc(sizeof(float) * V);             /* per-vertex diffuse */
     uint64_t *zbuf = (uint64_t *)malloc(sizeof(uint64_t) * Ho * Wo);
-    if (!clipw || !zn || !fx || !ok || !pc || !nc || !dv || !zbuf) { err = 1; }
+    if (!clipc || !clipw || !zn || !fx || !ok || !pc || !nc || !dv || !zbuf) { err = 1; }
     else {
     for (int i = 0; i < Ho * Wo; ++i) zbuf[i] = ~(uint64_t)0;
     for (int v = 0; v < V; ++v) {
@@ -89,6 +131,7 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
       nn = nn > 1e-12f ? nn : 1e-12f;
       dv[v] = clampf(-(nc[v * 3 + 2] / nn), 0.f, 1.f);
       float w = c[3];
+      for (int r = 0; r < 4; ++r) clipc[v * 4 + r] = c[r];
       clipw[v] = w;
       ok[v] = 0;
       if (w > 0.f) {
@@ -105,7 +148,20 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
     }
     for (int t = 0; t < F; ++t) {
       int i0 = m->faces[t * 3], i1 = m->faces[t * 3 + 1], i2 = m->faces[t * 3 + 2];
-      if (!(ok[i0] && ok[i1] && ok[i2])) continue;
+      if (!(ok[i0] && ok[i1] && ok[i2])) {
+        if (!(clipw[i0] > 0.f || clipw[i1] > 0.f || clipw[i2] > 0.f)) continue;   /* entirely behind the camera */
+        clip_tri T = clip_setup(clipc + i0 * 4, clipc + i1 * 4, clipc + i2 * 4, 0.5f * (float)Wo, 0.5f * (float)Ho);
+        if (!T.valid) continue;
+        for (int j = 0; j < Ho; ++j)
+          for (int i = 0; i < Wo; ++i) {
+            float l[3], zp;
+            if (!clip_eval(&T, i, j, l, &zp)) continue;
+            uint64_t key = ((uint64_t)ordered_key(zp) << 32) | (uint32_t)t;
+            uint64_t *zb = &zbuf[j * Wo + i];
+            if (key < *zb) *zb = key;
+          }
+        continue;
+      }
       int64_t X0 = fx[i0 * 2], Y0 = fx[i0 * 2 + 1], X1 = fx[i1 * 2], Y1 = fx[i1 * 2 + 1], X2 = fx[i2 * 2], Y2 = fx[i2 * 2 + 1];
       int64_t area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
       if (area == 0) continue;
@@ -153,6 +209,14 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
         if (key != ~(uint64_t)0) {
           int t = (int)(uint32_t)(key & 0xffffffffu);
           int i0 = m->faces[t * 3], i1 = m->faces[t * 3 + 1], i2 = m->faces[t * 3 + 2];
+          float u, v, w2, zp;
+          if (!(ok[i0] && ok[i1] && ok[i2])) {     /* straddles the camera plane: weights from the homogeneous edge functions */
+            clip_tri T = clip_setup(clipc + i0 * 4, clipc + i1 * 4, clipc + i2 * 4, 0.5f * (float)Wo, 0.5f * (float)Ho);
+            float l[3];
+            (void)clip_eval(&T, i, j, l, &zp);
+            float ls = (l[0] + l[1]) + l[2];
+            u = l[0] / ls; v = l[1] / ls; w2 = (1.f - u) - v;
+          } else {
           int64_t X0 = fx[i0 * 2], Y0 = fx[i0 * 2 + 1], X1 = fx[i1 * 2], Y1 = fx[i1 * 2 + 1], X2 = fx[i2 * 2], Y2 = fx[i2 * 2 + 1];
           int64_t area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
           int64_t s = area > 0 ? 1 : -1;
@@ -163,10 +227,11 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
           int64_t e2 = s * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
           float fa = (float)area;
           float b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
-          float zp = fmaf(b2, zn[i2], fmaf(b1, zn[i1], b0 * zn[i0]));
+          zp = fmaf(b2, zn[i2], fmaf(b1, zn[i1], b0 * zn[i0]));
           float q0 = b0 / clipw[i0], q1 = b1 / clipw[i1], q2 = b2 / clipw[i2];
           float qs = (q0 + q1) + q2;
-          float u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
+          u = q0 / qs; v = q1 / qs; w2 = (1.f - u) - v;
+          }
           r4[0] = u; r4[1] = v; r4[2] = zp; r4[3] = (float)(t + 1);
           for (int c = 0; c < 3; ++c) {
             p3[c] = fmaf(u, pc[i0 * 3 + c], fmaf(v, pc[i1 * 3 + c], w2 * pc[i2 * 3 + c]));
@@ -199,7 +264,7 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
       }
     }
     }
-    free(clipw); free(zn); free(fx); free(ok); free(pc); free(nc); free(dv); free(zbuf);
+    free(clipc); free(clipw); free(zn); free(fx); free(ok); free(pc); free(nc); free(dv); free(zbuf);
   }
   return err;
 }

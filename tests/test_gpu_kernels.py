@@ -77,6 +77,15 @@ def test_render_full_frame_and_edge_cases(sc, fp):
   poses[0, 2, 3] = -0.5
   _, got = _render_pair(sc, fp, poses[:1], None, (64, 64))
   assert float(got[1].abs().max()) == 0.0
+  # object THROUGH the camera plane (its far half in front of the camera, the rest behind): triangles with a vertex at w <= 0 are
+  # rasterised in homogeneous coordinates (nvdiffrast clips them), same arithmetic on both sides, full frame and one crop window
+  for tz, out, bbox in ((0.02, (120, 160), None), (0.05, (160, 160), torch.tensor([[200.0, 150.0, 440.0, 390.0]]))):
+    poses[0, :3, 3] = [0.01, -0.02, tz]
+    ref, got = _render_pair(sc, fp, poses[:1], bbox, out)
+    assert float((ref[1] > 0).float().mean()) > 0.2          # the near part of the object fills much of the view
+    for a, b in zip(ref, got):
+      frac, mx, _ = util.mismatch_report(a.numpy(), b.numpy(), 5e-6)
+      assert frac <= 5e-4, (tz, frac, mx)
   # zero hypotheses
   c, d, n = fp['U'].nvdiffrast_render(K=sc['K'], H=480, W=640, ob_in_cams=torch.zeros((0, 4, 4)).cuda(), mesh_tensors=util.to_dev(sc['mt']),
                                       output_size=(160, 160))

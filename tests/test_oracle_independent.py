@@ -118,6 +118,39 @@ def test_rasteriser_against_float64_point_in_triangle_and_plane_depth():
   assert c.min() >= -1e-6 and c.max() <= 1 + 1e-6 and np.abs(c.sum(1) - 1).max() < 1.0 + 1e-6   # convex blends of the vertex colours
 
 
+def test_rasteriser_triangles_through_the_camera_plane_against_the_analytic_plane():
+  """A ground plane (two triangles) that runs from 1 m BEHIND the camera to 3 m in front of it: every triangle has a vertex with
+  w <= 0, so the whole image comes from the homogeneous path of oracle/raster_c.c (nvdiffrast would clip against the near plane).
+  Expected, in float64: pixel row v below the horizon sees the plane y = h at depth z = h fy / (v - cy), inside |x| <= 1 and
+  z <= 3; nothing above the horizon; the near plane (z = 1 mm) only removes rows far below the image."""
+  from oracle.render import nvdiffrast_render
+  K = np.array([[300.0, 0, 79.5], [0, 300.0, 40.25], [0, 0, 1]])
+  H, W, h = 120, 160, 0.1
+  plane = np.array([[-1, h, -1], [1, h, -1], [1, h, 3], [-1, h, 3]], np.float32)
+  mt = dict(pos=torch.from_numpy(plane), faces=torch.tensor([[0, 1, 2], [0, 2, 3]], dtype=torch.int32),
+            vnormals=torch.tensor([[0, -1.0, 0]] * 4), vertex_color=torch.tensor([[1.0, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0]]))
+  extra = {}
+  _, depth, _ = nvdiffrast_render(K=K, H=H, W=W, ob_in_cams=np.eye(4, dtype=np.float32)[None], mesh_tensors=mt, use_light=False, extra=extra)
+  depth, xyz = depth[0].numpy(), extra['xyz_map'][0].numpy()
+  jj, ii = np.meshgrid(np.arange(H) + 0.5, np.arange(W) + 0.5, indexing='ij')
+  with np.errstate(divide='ignore'):
+    z = np.where(jj > K[1, 2], h * K[1, 1] / (jj - K[1, 2]), np.inf)
+  x = (ii - K[0, 2]) * z / K[0, 0]
+  inside = (z <= 3.0) & (np.abs(x) <= 1.0)
+  below = jj > K[1, 2] + 1.5
+  zz, xx = np.where(below, z, 1.0), np.where(below, x, 0.0)
+  margin = (jj < K[1, 2] - 1.5) | (below & (np.abs(zz - 3.0) > 0.05) & (np.abs(np.abs(xx) - 1.0) > 0.02 * zz))     # away from the outline
+  assert inside[margin].sum() > 5000 and (~inside)[margin].sum() > 5000
+  assert np.array_equal(depth[margin] > 0, inside[margin])
+  cov = margin & inside
+  np.testing.assert_allclose(depth[cov], z[cov], rtol=2e-4)
+  np.testing.assert_allclose(xyz[cov][:, 1], h, atol=2e-5)
+  ex = np.abs(xyz[cov][:, 0] - x[cov]) / np.maximum(1.0, np.abs(x[cov]))
+  assert ex.max() < 2e-4, ex.max()
+  # the diagonal shared by the two triangles leaves no crack and no seam in depth
+  assert np.abs(np.diff(depth, axis=1))[cov[:, 1:] & cov[:, :-1]].max() < 1e-3
+
+
 def test_warp_nearest_definition_agrees_with_the_literal_kornia_chain_off_ties():
   """oracle/warp.py holds two restatements of the nearest-neighbour crop: the literal kornia 0.7.2 chain (normalise,
   invert, grid_sample, float32) and the float64 per-pixel definition the HIP kernel follows.  Away from exact .5 ties
