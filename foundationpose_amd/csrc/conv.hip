@@ -453,6 +453,8 @@ static int launch_two(fp_ctx *ctx, const ConvArgs &a, const f16 *zero_page, hipS
 
 bool conv_halo_supported(const ConvArgs &a);
 int launch_conv_halo(const ConvArgs &a, hipStream_t s);
+bool stem_supported(const ConvArgs &a);                     // stem.hip
+int launch_stem(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   FP_REQUIRE(a.Cin == 8 || a.Cin % 32 == 0, "conv: Cin=%d must be 8 or a multiple of 32", a.Cin);
@@ -467,6 +469,7 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const char *cls = halo ? "conv3x3_halo" : (a.KW == 3) ? "conv3x3_s2" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
   if (halo) return launch_conv_halo(a, s);
+  if (stem_supported(a)) return launch_stem(ctx, a, s);
   const bool bm128 = (a.Cout % 128 == 0);
   const f16 *zp = (const f16 *)ctx->zero_page;
   if (a.Cin == 8) {

@@ -1,6 +1,7 @@
-"""Pretty-print the JSON line of bench.py (stdin): value, ms/step, roofline, per-class times."""
+"""Pretty-print the JSON line of bench.py (file argument, else stdin): value, ms/step, roofline, per-class times."""
 import json, sys
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+text = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+d = json.loads([l for l in text.strip().splitlines() if l.startswith('{')][-1])
 print(f"{d['value']:.1f} hyp/s  {d['ms_per_step']:.2f} ms/step  halo {d['roofline']['achieved']:.0f} TF/s ({d['roofline']['frac']:.3f})")
 for k, v in d.get('kernel_classes', {}).items():
   tf = f"{v['tflops']:.0f} TF/s" if v['tflops'] else ''
