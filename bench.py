@@ -283,7 +283,7 @@ def main():
   timed_steps(single, args.steps, barrier, device, world)
   ctx.prof_enable(False)
   classes = {}
-  for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'render'):
+  for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'heads_wall', 'render'):
     r = ctx.prof_read(c)
     if r['launches']:
       classes[c] = {'ms_per_step': r['total_ms'] / args.steps, 'launches_per_step': r['launches'] / args.steps,
@@ -353,7 +353,8 @@ def main():
     }
     out['kernel_classes'] = classes       # HIP-event time per kernel class, from an untimed pass of the same K steps
     out['kernel_classes_note'] = ('linear / attention: RefineNet runs its two transformer heads on two streams, their launches overlap '
-                                  'and each counts its own span (sum > wall time); the convolution classes and render run alone')
+                                  'and each counts its own span (sum > wall time); heads_wall = first in-projection .. join of the heads on the main stream '
+                                  '(their wall-clock share, one span per network pass); the convolution classes and render run alone')
     out.update(extras)
     if not args.no_cpu_baseline and world == 1:        # timed on rank 0 of the single-GPU run only
       out['cpu_baseline'] = cpu_baseline()

@@ -596,6 +596,17 @@ extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int
     return rc;
   }
   a.ksplit = 0;
+  if (!out_f32 && a.M >= S2_MIN_PIXELS && s2_supported(a)) {       // the band-in-LDS form of the 3x3 stride-2 layers, as inside the networks
+    const size_t bytes = s2_packed_halfs(Cout, Cin) * sizeof(f16);
+    FP_TRY(fp_arena_ensure(ctx, bytes + 4096));
+    const size_t mark = ctx->arena.off;
+    f16 *pk = (f16 *)ctx->arena.take(bytes);
+    int rc = pk ? s2_pack_weights(a.w, Cout, Cin, a.Kpad, pk, (hipStream_t)stream) : FP_ENOMEM;
+    a.wpk = pk;
+    if (rc == FP_OK) rc = launch_conv(ctx, a, (hipStream_t)stream);
+    ctx->arena.off = mark;
+    return rc;
+  }
   return launch_conv(ctx, a, (hipStream_t)stream);
 }
 

@@ -205,8 +205,17 @@ struct ConvArgs {
   // fixed order and applies bias-free epilogue (the bias rides in split 0).  0 / nullptr: off.
   float *splitk = nullptr;
   int ksplit = 0;
+  // 3x3 stride-2 layers: the weights in the fragment order of conv_s2.hip (s2_pack_weights); nullptr: the implicit-GEMM kernel runs
+  const f16 *wpk = nullptr;
 };
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
+// conv_s2.hip: band-in-LDS form of the 3x3 stride-2 layers
+#define S2_MIN_PIXELS 2000      // below (1 .. 4 hypotheses at 20x20 outputs: the sizes whose 3x3 stride-1 layers run split-K) the implicit-GEMM kernel with its 64-pixel tail tiles runs
+bool s2_supported(const ConvArgs &a);
+int s2_ct_for(int Cout);
+size_t s2_packed_halfs(int Cout, int Cin);
+int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s);
+int launch_conv_s2(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
 // Column of token t inside the transposed V image [b][4][128][416].  Within each group of 16 tokens the order is
 // {0-3, 8-11, 4-7, 12-15}: the 8 keys that one lane half of the attention kernel's P^T operand carries (the S^T

@@ -470,6 +470,7 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   ProfScope ps(ctx, s, cls, flops);
   if (halo) return launch_conv_halo(a, s);
   if (stem_supported(a)) return launch_stem(ctx, a, s);
+  if (a.wpk && a.M >= S2_MIN_PIXELS && s2_supported(a)) return launch_conv_s2(ctx, a, s);
   const bool bm128 = (a.Cout % 128 == 0);
   const f16 *zp = (const f16 *)ctx->zero_page;
   if (a.Cin == 8) {

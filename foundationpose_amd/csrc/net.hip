@@ -10,6 +10,7 @@
 
 struct ConvW {
   f16 *w = nullptr;
+  f16 *wpk = nullptr;     // 3x3 stride-2 layers: the same weights in the fragment order of conv_s2.hip
   float *bias = nullptr;
   int Cin = 0, Cout = 0, K = 1, Kpad = 0, stride = 1;
 };
@@ -128,6 +129,14 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
   out->stride = stride;
   FP_TRY(upload(net, hw, &out->w));
   FP_TRY(upload(net, hb, &out->bias));
+  if (K == 3 && stride == 2 && CinP % 16 == 0 && s2_ct_for(Cout) != 0) {
+    void *pk = nullptr;
+    FP_CHECK_HIP(hipMalloc(&pk, s2_packed_halfs(Cout, CinP) * sizeof(f16)));
+    net->allocs.push_back(pk);
+    out->wpk = (f16 *)pk;
+    FP_TRY(s2_pack_weights(out->w, Cout, CinP, Kpad, out->wpk, nullptr));
+    FP_CHECK_HIP(hipStreamSynchronize(nullptr));
+  }
   return FP_OK;
 }
 
@@ -300,6 +309,7 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
   const ConvW &w = *c.cw;
   a.in = c.in;
   a.w = w.w;
+  a.wpk = w.wpk;
   a.bias = w.bias;
   a.res = c.res;
   a.post_add = c.post_add;
@@ -445,6 +455,7 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     }
     // in-projections of BOTH heads: the tokens are staged once per workgroup for 512 output columns of either head
     const LinP *q_[2] = {&net->heads[0].q, &net->heads[1].q}, *k_[2] = {&net->heads[0].k, &net->heads[1].k}, *v_[2] = {&net->heads[0].v, &net->heads[1].v};
+    ProfScope wall(ctx, s, "heads_wall", 0.0);      // first in-projection .. join of both heads, on the main stream: the heads' share of wall time
     FP_TRY(run_qkv(ctx, q_, k_, v_, 2, tok, N, qk, vt, s));
     static const bool serial_heads = getenv("FP_HEADS_SERIAL") != nullptr;      // A/B timing knob
     StreamFanout fo(ctx, s, serial_heads ? 1 : 2);
@@ -568,6 +579,7 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
     TAKE(mean, float, (size_t)N * 512);
     const LinP *q_[1] = {&net->att_q}, *k_[1] = {&net->att_k}, *v_[1] = {&net->att_v};
     f16 *qk_[1] = {qk}, *vt_[1] = {vt};
+    ProfScope wall(ctx, s, "heads_wall", 0.0);
     FP_TRY(run_qkv(ctx, q_, k_, v_, 1, tok, N, qk_, vt_, s));
     FP_TRY(launch_attention(ctx, qk, vt, N, 400, att, s));
     // mean over tokens commutes with out_proj (score_network.py:73-74)
