@@ -69,10 +69,6 @@ def nvdiffrast_render(K=None, H=None, W=None, ob_in_cams=None, glctx=None, conte
       logging.info("created context")
     else:
       raise NotImplementedError
-  if projection_mat is not None:
-    raise NotImplementedError('projection_mat override is not supported; pass K,H,W')
-  if light_color is not None or light_dir is None or not np.allclose(np.asarray(light_dir, dtype=float), [0, 0, 1]):
-    raise NotImplementedError('only the reference defaults light_dir=[0,0,1], light_color=None are implemented')
   if mesh_tensors is None:
     mesh_tensors = make_mesh_tensors(mesh)
   ctx = _ctx_of(glctx)
@@ -93,9 +89,37 @@ def nvdiffrast_render(K=None, H=None, W=None, ob_in_cams=None, glctx=None, conte
   depth = torch.empty((N, h, w), dtype=torch.float, device=dev)
   xyz = torch.empty((N, h, w, 3), dtype=torch.float, device=dev)
   normal = torch.empty((N, h, w, 3), dtype=torch.float, device=dev) if get_normal else None
-  Kd, Kp = k_ptr(K)
-  check(lib().fp_render(ctx.handle, dm.handle, ptr(poses), N, Kp, int(H), int(W), ptr(bb), h, w, 1 if use_light else 0,
-                        float(w_ambient), float(w_diffuse), ptr(color), ptr(depth), ptr(normal), ptr(xyz), stream_ptr(dev)))
+  default_light = light_color is None and light_dir is not None and np.array_equal(np.asarray(light_dir, dtype=float).reshape(-1), [0, 0, 1])
+  if projection_mat is None and (default_light or not use_light):
+    Kd, Kp = k_ptr(K)
+    check(lib().fp_render(ctx.handle, dm.handle, ptr(poses), N, Kp, int(H), int(W), ptr(bb), h, w, 1 if use_light else 0,
+                          float(w_ambient), float(w_diffuse), ptr(color), ptr(depth), ptr(normal), ptr(xyz), stream_ptr(dev)))
+  else:
+    # light_dir / light_pos / light_color / projection_mat (src/Utils.py:159-161,200-211) travel in fp_render_opts
+    o = _lib.FpRenderOpts()
+    o.use_light, o.w_ambient, o.w_diffuse = (1 if use_light else 0), float(w_ambient), float(w_diffuse)
+    if default_light:
+      o.light_mode = 0
+    elif light_dir is not None:
+      o.light_mode = 1
+      o.light_vec[:] = [-float(x) for x in np.asarray(light_dir, dtype=np.float32).reshape(3)]      # light_dir_neg
+    else:
+      o.light_mode = 2
+      o.light_vec[:] = [float(x) for x in np.asarray(light_pos, dtype=np.float32).reshape(3)]
+    if light_color is not None:
+      o.has_light_color = 1
+      o.light_color[:] = [float(x) for x in np.asarray(torch.as_tensor(light_color).cpu(), dtype=np.float32).reshape(3)]
+    if projection_mat is not None:
+      pm = np.asarray(torch.as_tensor(projection_mat).cpu(), dtype=np.float64).reshape(-1, 4, 4)
+      if len(pm) != 1:
+        raise NotImplementedError('one projection_mat per call (the reference broadcasts a single matrix in every in-repo call)')
+      o.has_projection = 1
+      o.projection[:] = [float(x) for x in pm[0].reshape(16)]
+    Kp = None
+    if K is not None:
+      Kd, Kp = k_ptr(K)
+    check(lib().fp_render_ex(ctx.handle, dm.handle, ptr(poses), N, Kp, int(H), int(W), ptr(bb), h, w, ctypes.byref(o), ptr(color), ptr(depth),
+                             ptr(normal), ptr(xyz), stream_ptr(dev)))
   extra['xyz_map'] = xyz
   return color, depth, normal
 

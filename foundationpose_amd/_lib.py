@@ -27,6 +27,12 @@ class FpRefineCfg(Structure):
               ('trans_normalizer', c_float * 3), ('rot_normalizer', c_float)]
 
 
+class FpRenderOpts(Structure):
+  """fp_render_opts (include/foundationpose_amd.h): the non-default arguments of nvdiffrast_render."""
+  _fields_ = [('use_light', c_int), ('w_ambient', c_float), ('w_diffuse', c_float), ('light_mode', c_int), ('light_vec', c_float * 3),
+              ('has_light_color', c_int), ('light_color', c_float * 3), ('has_projection', c_int), ('projection', c_double * 16)]
+
+
 class FpObjectBatch(Structure):
   _fields_ = [('mesh', c_void_p), ('d_rgb', c_void_p), ('d_geom', c_void_p), ('H', c_int), ('W', c_int), ('K', c_void_p),
               ('mesh_diameter', c_double), ('n', c_int)]
@@ -47,6 +53,7 @@ _PROTOS = {
   'fp_mesh_destroy': (c_int, [c_void_p]),
   'fp_crop_window_tf': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_double, c_double, c_int, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_render': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'fp_render_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(FpRenderOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
   'fp_render_net': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_float, c_void_p, c_void_p]),
   'fp_crop_observed': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p, c_void_p]),
   'fp_erode_depth': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
@@ -62,6 +69,7 @@ _PROTOS = {
   'fp_score_features': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_score_tail': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_pose_update': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p]),
+  'fp_pose_update_deepim': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p]),
   'fp_refine_predict': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, POINTER(FpRefineCfg), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_refine_predict_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, POINTER(FpRefineCfg), c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_score_predict_features_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, c_double, c_int, c_void_p, c_void_p, c_void_p]),

@@ -266,6 +266,31 @@ extern "C" int fp_render(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses,
   return launch_render(ctx, a, (hipStream_t)stream);
 }
 
+extern "C" int fp_render_ex(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+                            const float *d_bbox2d, int out_h, int out_w, const fp_render_opts *opts, float *d_color, float *d_depth,
+                            float *d_normal, float *d_xyz, void *stream) {
+  FP_REQUIRE(ctx, "fp_render_ex: null ctx");
+  if (!opts) return fp_render(ctx, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w, 0, 0.8f, 0.5f, d_color, d_depth, d_normal, d_xyz, stream);
+  FP_REQUIRE(opts->light_mode >= 0 && opts->light_mode <= 2, "fp_render_ex: light_mode %d unknown", opts->light_mode);
+  static const double unit_k[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  FP_REQUIRE(K || opts->has_projection, "fp_render_ex: neither K nor a projection matrix");
+  RenderArgs a;
+  FP_TRY(fill_render(a, mesh, d_poses, N, K ? K : unit_k, H, W, d_bbox2d, out_h, out_w));
+  a.use_light = opts->use_light;
+  a.w_ambient = opts->w_ambient;
+  a.w_diffuse = opts->w_diffuse;
+  a.light_mode = opts->light_mode;
+  a.has_light_color = opts->has_light_color;
+  for (int c = 0; c < 3; ++c) a.light_vec[c] = opts->light_vec[c], a.light_color[c] = opts->light_color[c];
+  a.has_proj = opts->has_projection;
+  for (int i = 0; i < 16; ++i) a.proj[i] = opts->projection[i];
+  a.color = d_color;
+  a.depth = d_depth;
+  a.normal = d_normal;
+  a.xyz = d_xyz;
+  return launch_render(ctx, a, (hipStream_t)stream);
+}
+
 // vscratch: optional N * V * 16 bytes for the vertex pre-pass (nullptr: every triangle transforms its own vertices)
 static int render_net_impl(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
                            const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
@@ -359,8 +384,17 @@ extern "C" int fp_pose_update(fp_ctx *ctx, const float *d_poseA, const float *d_
                               void *stream) {
   FP_REQUIRE(ctx && d_poseA && d_trans && d_rot && d_pose_out, "fp_pose_update: null argument");
   float t0 = tn ? tn[0] : 1.f, t1 = tn ? tn[1] : 1.f, t2 = tn ? tn[2] : 1.f;
+  FP_REQUIRE(trans_rep_tanh == 0 || trans_rep_tanh == 1, "fp_pose_update: trans_rep_tanh must be 0 or 1 (trans_rep='deepim': fp_pose_update_deepim)");
   return launch_pose_update(d_poseA, d_trans, d_rot, N, rot_dim, trans_rep_tanh, t0, t1, t2, rot_normalizer, trans_scale, d_pose_out,
                             (hipStream_t)stream);
+}
+
+extern "C" int fp_pose_update_deepim(fp_ctx *ctx, const float *d_poseA, const float *d_trans, const float *d_rot, int N, int rot_dim,
+                                     const float *d_tf_to_crops, const double *K, float input_resize, float rot_normalizer, float trans_scale,
+                                     float *d_pose_out, void *stream) {
+  FP_REQUIRE(ctx && d_poseA && d_trans && d_rot && d_pose_out && d_tf_to_crops && K, "fp_pose_update_deepim: null argument");
+  return launch_pose_update(d_poseA, d_trans, d_rot, N, rot_dim, 2, 1.f, 1.f, 1.f, rot_normalizer, trans_scale, d_pose_out, (hipStream_t)stream,
+                            d_tf_to_crops, K, input_resize);
 }
 
 // ---- composed loops --------------------------------------------------------------------------------
@@ -469,11 +503,13 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
       for (int o = 0; o < n_obj;) {
         const float trans_scale = cfg->normalize_xyz ? (float)(objs[o].mesh_diameter / 2) : 1.f;
         int cnt = 0, e = o;
-        while (e < n_obj && (cfg->normalize_xyz ? (float)(objs[e].mesh_diameter / 2) : 1.f) == trans_scale) cnt += objs[e++].n;
+        // (trans_rep='deepim' also needs the object's intrinsics: one launch per object)
+        while (e < n_obj && (cfg->normalize_xyz ? (float)(objs[e].mesh_diameter / 2) : 1.f) == trans_scale && (cfg->trans_rep_tanh != 2 || e == o))
+          cnt += objs[e++].n;
         if (cnt > 0)
           FP_TRY(launch_pose_update(d_poses + (size_t)off * 16, tr + (size_t)off * 3, ro + (size_t)off * rot_dim, cnt, rot_dim,
                                     cfg->trans_rep_tanh, cfg->trans_normalizer[0], cfg->trans_normalizer[1], cfg->trans_normalizer[2],
-                                    cfg->rot_normalizer, trans_scale, pose_tmp + (size_t)off * 16, s));
+                                    cfg->rot_normalizer, trans_scale, pose_tmp + (size_t)off * 16, s, tf + (size_t)off * 9, objs[o].K, 160.f));
         off += cnt;
         o = e;
       }

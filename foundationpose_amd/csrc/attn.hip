@@ -706,17 +706,48 @@ int launch_argmax(const float *logits, int groups, int L, int32_t *out, hipStrea
 }
 
 // pose update (predict_pose_refine.py:195-231): float32, mirrors oracle/predict.py:pose_update
+struct DeepimArgs {        // trans_rep='deepim' (predict_pose_refine.py:201-215): the crop transforms of this pass, the intrinsics, input_resize[0]
+  const float *tf;         // N x 9
+  float K[9];
+  float resize;
+};
+
+__device__ __forceinline__ void inv3x3(const float *m, float *o) {     // adjugate / determinant
+  const float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const float id = 1.f / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+  o[0] = c00 * id, o[1] = (m[2] * m[7] - m[1] * m[8]) * id, o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  o[3] = c01 * id, o[4] = (m[0] * m[8] - m[2] * m[6]) * id, o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  o[6] = c02 * id, o[7] = (m[1] * m[6] - m[0] * m[7]) * id, o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
 __global__ void pose_update_kernel(const float *__restrict__ poseA, const float *__restrict__ trans, const float *__restrict__ rot,
                                    int N, int rot_dim, int trans_tanh, float tn0, float tn1, float tn2, float rot_normalizer,
-                                   float trans_scale, float *__restrict__ outp) {
+                                   float trans_scale, DeepimArgs dp, float *__restrict__ outp) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= N) return;
   const float *A = poseA + (size_t)b * 16;
   float td[3] = {trans[b * 3], trans[b * 3 + 1], trans[b * 3 + 2]};
-  if (trans_tanh) {
+  if (trans_tanh == 1) {
     td[0] = tanhf(td[0]) * tn0;
     td[1] = tanhf(td[1]) * tn1;
     td[2] = tanhf(td[2]) * tn2;
+  } else if (trans_tanh == 2) {
+    // deepim: the network predicts the shift of the projected centre in the crop (in units of the crop size) and the depth ratio
+    const float *tf = dp.tf + (size_t)b * 9, *K = dp.K;
+    const float cx = A[3], cy = A[7], cz = A[11];
+    const float z_pred = td[2] * cz;
+    float uvw[3];
+    for (int r = 0; r < 3; ++r) uvw[r] = K[r * 3] * cx + K[r * 3 + 1] * cy + K[r * 3 + 2] * cz;
+    const float u = uvw[0] / uvw[2], v = uvw[1] / uvw[2], w1 = uvw[2] / uvw[2];
+    const float uc = tf[0] * u + tf[1] * v + tf[2] * w1 + td[0] * dp.resize;      // uvA_crop + trans[:2] * input_resize[0]
+    const float vc = tf[3] * u + tf[4] * v + tf[5] * w1 + td[1] * dp.resize;
+    float ti[9], Ki[9];
+    inv3x3(tf, ti);
+    inv3x3(K, Ki);
+    const float up = ti[0] * uc + ti[1] * vc + ti[2], vp = ti[3] * uc + ti[4] * vc + ti[5];      // transform_pts(uv_pred_crop, tf^-1)
+    td[0] = (Ki[0] * up + Ki[1] * vp + Ki[2]) * z_pred - cx;
+    td[1] = (Ki[3] * up + Ki[4] * vp + Ki[5]) * z_pred - cy;
+    td[2] = (Ki[6] * up + Ki[7] * vp + Ki[8]) * z_pred - cz;
   }
   td[0] *= trans_scale;
   td[1] *= trans_scale;
@@ -767,11 +798,18 @@ __global__ void pose_update_kernel(const float *__restrict__ poseA, const float 
 }
 
 int launch_pose_update(const float *poseA, const float *trans, const float *rot, int N, int rot_dim, int trans_tanh, float tn0,
-                       float tn1, float tn2, float rot_normalizer, float trans_scale, float *out, hipStream_t s) {
+                       float tn1, float tn2, float rot_normalizer, float trans_scale, float *out, hipStream_t s, const float *tf,
+                       const double *K, float resize) {
   FP_REQUIRE(rot_dim == 3 || rot_dim == 6, "pose_update: rot_dim must be 3 or 6");
+  FP_REQUIRE(trans_tanh >= 0 && trans_tanh <= 2, "pose_update: trans mode %d unknown (0 raw, 1 tanh, 2 deepim)", trans_tanh);
+  FP_REQUIRE(trans_tanh != 2 || (tf && K), "pose_update: trans_rep='deepim' needs the crop transforms and K");
   if (N == 0) return FP_OK;
+  DeepimArgs dp;
+  dp.tf = tf;
+  dp.resize = resize;
+  for (int i = 0; i < 9; ++i) dp.K[i] = K ? (float)K[i] : 0.f;
   hipLaunchKernelGGL(pose_update_kernel, dim3((N + 63) / 64), dim3(64), 0, s, poseA, trans, rot, N, rot_dim, trans_tanh, tn0, tn1, tn2,
-                     rot_normalizer, trans_scale, out);
+                     rot_normalizer, trans_scale, dp, out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -256,8 +256,10 @@ int launch_token_mean(const f16 *x, int Bn, int T, float *out, hipStream_t s);
 int launch_small_linear(const float *x, const float *w, const float *wt, const float *b, int M, int K, int N, float *out, hipStream_t s);
 int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s);
 int launch_argmax(const float *logits, int groups, int L, int32_t *out, hipStream_t s);
+// trans_tanh: 0 raw, 1 tanh * trans_normalizer, 2 trans_rep='deepim' (needs tf N x 9, K, resize = input_resize[0])
 int launch_pose_update(const float *poseA, const float *trans, const float *rot, int N, int rot_dim, int trans_tanh,
-                       float tn0, float tn1, float tn2, float rot_normalizer, float trans_scale, float *out, hipStream_t s);
+                       float tn0, float tn1, float tn2, float rot_normalizer, float trans_scale, float *out, hipStream_t s,
+                       const float *tf = nullptr, const double *K = nullptr, float resize = 160.f);
 
 struct RenderArgs {
   MeshDev mesh;
@@ -271,6 +273,13 @@ struct RenderArgs {
   float mesh_diameter, invalid_thres;
   int normalize_xyz;
   void *vbuf = nullptr;                 // optional scratch, N * V * 16 B: transformed vertices (render pre-pass)
+  // non-default lighting / projection of nvdiffrast_render (src/Utils.py:159-162,200-211)
+  int light_mode = 0;                   // 0: light_dir = (0,0,1), the default; 1: direction light_vec = -light_dir; 2: point light at light_vec (light_dir=None)
+  float light_vec[3] = {0.f, 0.f, -1.f};
+  int has_light_color = 0;              // 0: the diffuse term takes the surface colour (light_color=None)
+  float light_color[3] = {1.f, 1.f, 1.f};
+  int has_proj = 0;                     // 1: proj replaces projection_matrix_from_intrinsics(K, H, W, 0.001, 100)
+  double proj[16] = {0};
 };
 int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s);
 int launch_crop_window_tf(const float *poses, int N, const double *K, double crop_ratio, double diameter, int ow, int oh, float *tf,

@@ -122,6 +122,8 @@ __device__ void clip_matrix(const RenderArgs &a, int b, const float *pose, float
                   0, 2 * a.K[4] / H, (2 * a.K[5] - H) / H, 0,
                   0, 0, -(zf + zn) / (zf - zn), -2 * (zf * zn) / (zf - zn),
                   0, 0, -1, 0};
+  if (a.has_proj)                       // projection_mat given by the caller (src/Utils.py:159-161)
+    for (int i = 0; i < 16; ++i) P[i] = a.proj[i];
   double G[16];  // glcam_in_cvcam @ ob_in_cam : negate rows 1,2
   for (int c = 0; c < 4; ++c) {
     G[c] = pose[c];
@@ -391,7 +393,17 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
         nc[k][2] = fmaf(P8, nx, fmaf(P9, ny, P10 * nz));
         float nn = sqrtf(fmaf(nc[k][0], nc[k][0], fmaf(nc[k][1], nc[k][1], nc[k][2] * nc[k][2])));
         nn = nn > 1e-12f ? nn : 1e-12f;
-        dv[k] = fminf(fmaxf(-(nc[k][2] / nn), 0.f), 1.f);
+        if (a.light_mode == 0) {
+          dv[k] = fminf(fmaxf(-(nc[k][2] / nn), 0.f), 1.f);
+        } else {                        // src/Utils.py:200-205: normalize(vnormals_cam) . normalize(-light_dir | light_pos - pts_cam), clipped to [0,1]
+          float L[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) L[c] = a.light_mode == 1 ? a.light_vec[c] : a.light_vec[c] - pc[k][c];
+          float ln = sqrtf(fmaf(L[0], L[0], fmaf(L[1], L[1], L[2] * L[2])));
+          ln = ln > 1e-12f ? ln : 1e-12f;
+          const float dt = fmaf(nc[k][0] / nn, L[0] / ln, fmaf(nc[k][1] / nn, L[1] / ln, (nc[k][2] / nn) * (L[2] / ln)));
+          dv[k] = fminf(fmaxf(dt, 0.f), 1.f);
+        }
       }
       float base[3];
 #pragma unroll
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
         float d = fmaf(u, dv[0], fmaf(v, dv[1], w2 * dv[2]));
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          base[c] = __fadd_rn(__fmul_rn(base[c], a.w_ambient), __fmul_rn(__fmul_rn(d, base[c]), a.w_diffuse));
+          base[c] = __fadd_rn(__fmul_rn(base[c], a.w_ambient), __fmul_rn(__fmul_rn(d, a.has_light_color ? a.light_color[c] : base[c]), a.w_diffuse));
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) col[c] = fminf(fmaxf(base[c], 0.f), 1.f);

@@ -114,7 +114,8 @@ class PoseRefinePredictor:
     c = FpRefineCfg()
     c.crop_ratio = float(self.cfg['crop_ratio'])
     c.normalize_xyz = 1 if self.cfg['normalize_xyz'] else 0
-    c.trans_rep_tanh = 1 if (self.cfg['trans_rep'] == 'tracknet' and not self.cfg['normalize_xyz']) else 0
+    # 0: raw head output, 1: tanh * trans_normalizer (tracknet without normalize_xyz), 2: deepim (predict_pose_refine.py:195-215)
+    c.trans_rep_tanh = 2 if self.cfg['trans_rep'] == 'deepim' else (1 if (self.cfg['trans_rep'] == 'tracknet' and not self.cfg['normalize_xyz']) else 0)
     tn = self.cfg['trans_normalizer']
     tn = [float(tn)] * 3 if isinstance(tn, (float, int)) else [float(x) for x in tn]
     for i in range(3):
@@ -134,13 +135,22 @@ class PoseRefinePredictor:
     return dict(trans=trans, rot=rot)
 
   @torch.inference_mode()
-  def update_poses(self, poseA, trans, rot, mesh_diameter):
-    """predict_pose_refine.py:195-231: head outputs -> B_in_cam (egocentric delta applied to poseA)."""
+  def update_poses(self, poseA, trans, rot, mesh_diameter, tf_to_crops=None, K=None):
+    """predict_pose_refine.py:195-231: head outputs -> B_in_cam (egocentric delta applied to poseA).  trans_rep='deepim'
+    (:201-215) also needs the pass's crop transforms (pose_data.tf_to_crops) and the intrinsics."""
     c = self._c_cfg()
     poseA = poseA.contiguous()
     out = torch.empty_like(poseA)
     tn = np.array([c.trans_normalizer[i] for i in range(3)], dtype=np.float32)
     scale = float(mesh_diameter) / 2 if c.normalize_xyz else 1.0
+    if c.trans_rep_tanh == 2:
+      if tf_to_crops is None or K is None:
+        raise ValueError("trans_rep='deepim': update_poses needs tf_to_crops and K")
+      tf = torch.as_tensor(tf_to_crops, device=poseA.device, dtype=torch.float).reshape(-1, 9).contiguous()
+      Kd, Kp = k_ptr(K)
+      check(lib().fp_pose_update_deepim(self.ctx.handle, ptr(poseA), ptr(trans), ptr(rot), len(poseA), self.model.rot_dim, ptr(tf), Kp,
+                                        float(self.cfg['input_resize'][0]), c.rot_normalizer, scale, ptr(out), stream_ptr(poseA.device)))
+      return out
     check(lib().fp_pose_update(self.ctx.handle, ptr(poseA), ptr(trans), ptr(rot), len(poseA), self.model.rot_dim, c.trans_rep_tanh,
                                tn.ctypes.data, c.rot_normalizer, scale, ptr(out), stream_ptr(poseA.device)))
     return out
@@ -169,8 +179,6 @@ class PoseRefinePredictor:
     returns (B_in_cams (N,4,4) float tensor on the device, vis or None)
     '''
     logging.info(f'ob_in_cams:{np.shape(ob_in_cams)}')
-    if self.cfg['trans_rep'] not in ('tracknet',) and self.cfg['trans_rep'] == 'deepim':
-      raise NotImplementedError("trans_rep='deepim' (non-default branch, predict_pose_refine.py:201-215) is not implemented")
     if self.cfg['rot_rep'] not in ('axis_angle', '6d'):
       raise RuntimeError
     ctx = _ctx_of(glctx, self.device) if glctx is not None else self.ctx

@@ -66,6 +66,22 @@ int fp_render(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, con
               float *d_color /* N*h*w*3 */, float *d_depth /* N*h*w */, float *d_normal /* N*h*w*3 */,
               float *d_xyz /* N*h*w*3 */, void *stream);
 
+/* The same with the non-default arguments of nvdiffrast_render: light_dir / light_pos / light_color (src/Utils.py:200-211)
+ * and projection_mat (src/Utils.py:159-161).  opts == NULL is fp_render with use_light = 0. */
+typedef struct fp_render_opts {
+  int use_light;
+  float w_ambient, w_diffuse;
+  int light_mode;          /* 0: light_dir = (0,0,1) (the default); 1: light_vec = -light_dir; 2: light_vec = light_pos (light_dir=None) */
+  float light_vec[3];
+  int has_light_color;     /* 0: light_color=None (the diffuse term takes the surface colour) */
+  float light_color[3];
+  int has_projection;      /* 1: projection (row-major 4x4, the reference's projection_mat) replaces the matrix derived from K */
+  double projection[16];
+} fp_render_opts;
+int fp_render_ex(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
+                 const float *d_bbox2d, int out_h, int out_w, const fp_render_opts *opts,
+                 float *d_color, float *d_depth, float *d_normal, float *d_xyz, void *stream);
+
 /* ---- a10/a13/a18 side A fused: render + rgb scaling + xyz centring / normalising / invalidating
  *      (h5_dataset.py:92-99 | :151-156) straight into a net tensor.  invalid_thres = 0.001
  *      (refiner) or 0.1 (scorer). ------------------------------------------------------------- */
@@ -129,10 +145,17 @@ int fp_score_tail(fp_ctx *ctx, const fp_net *net, const float *d_feats, int grou
                   int32_t *d_argmax, void *stream);
 
 /* a16: pose update (predict_pose_refine.py:195-231 + so3_exp_map + egocentric_delta_pose_to_pose).
- * trans_rep_tanh: 1 -> tanh(trans)*trans_normalizer (normalize_xyz False), 0 -> raw.  rot_dim 3|6. */
+ * trans_rep_tanh: 1 -> tanh(trans)*trans_normalizer (normalize_xyz False), 0 -> raw.  rot_dim 3|6.
+ * (fp_refine_cfg.trans_rep_tanh also takes 2 = trans_rep 'deepim', see fp_pose_update_deepim.) */
 int fp_pose_update(fp_ctx *ctx, const float *d_poseA, const float *d_trans, const float *d_rot, int N, int rot_dim,
                    int trans_rep_tanh, const float *trans_normalizer3, float rot_normalizer, float trans_scale,
                    float *d_pose_out, void *stream);
+
+/* a16, trans_rep='deepim' (predict_pose_refine.py:201-215): trans[:, :2] shifts the projected centre inside the crop (units of
+ * input_resize), trans[:, 2] scales its depth; d_tf_to_crops N*9 are the crop transforms of the pass, K the intrinsics. */
+int fp_pose_update_deepim(fp_ctx *ctx, const float *d_poseA, const float *d_trans, const float *d_rot, int N, int rot_dim,
+                          const float *d_tf_to_crops, const double *K, float input_resize, float rot_normalizer, float trans_scale,
+                          float *d_pose_out, void *stream);
 
 /* a17: PoseRefinePredictor.predict inner loop (predict_pose_refine.py:182-234), `iteration` rounds of
  * crop-window -> render -> observed crop -> RefineNet -> pose update, entirely on the device.

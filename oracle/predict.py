@@ -93,8 +93,9 @@ def make_crop_data_batch_score(cfg, ob_in_cams, mesh_tensors, rgb, depth, K, mes
               poseA=poseA, tf_to_crops=tf_to_crops)
 
 
-def pose_update(cfg, poseA, trans, rot, mesh_diameter):
-  """predict_pose_refine.py:195-231 (tracknet / axis_angle|6d branches)."""
+def pose_update(cfg, poseA, trans, rot, mesh_diameter, tf_to_crops=None, Ks=None):
+  """predict_pose_refine.py:195-231 (tracknet / deepim; axis_angle|6d branches).  deepim needs the pass's tf_to_crops (N,3,3) and
+  Ks (N or 1,3,3), as the reference reads them from pose_data."""
   if cfg['trans_rep'] == 'tracknet':
     if not cfg['normalize_xyz']:
       tn = cfg['trans_normalizer']
@@ -103,6 +104,25 @@ def pose_update(cfg, poseA, trans, rot, mesh_diameter):
       trans_delta = torch.tanh(trans) * tn
     else:
       trans_delta = trans
+  elif cfg['trans_rep'] == 'deepim':                     # predict_pose_refine.py:201-215
+    n = len(trans)
+    tf = torch.as_tensor(tf_to_crops, dtype=torch.float32).reshape(-1, 3, 3)
+    Kt = torch.as_tensor(Ks, dtype=torch.float32).reshape(-1, 3, 3).expand(n, 3, 3)
+
+    def project_and_transform_to_crop(centers):
+      uvs = (Kt @ centers.reshape(-1, 3, 1)).reshape(-1, 3)
+      uvs = uvs / uvs[:, 2:3]
+      uvs = (tf @ uvs.reshape(-1, 3, 1)).reshape(-1, 3)
+      return uvs[:, :2]
+
+    z_pred = trans[:, 2] * poseA[..., 2, 3]
+    uvA_crop = project_and_transform_to_crop(poseA[..., :3, 3])
+    uv_pred_crop = uvA_crop + trans[:, :2] * cfg['input_resize'][0]
+    tfi = tf.inverse()
+    uv_pred = (tfi[:, :2, :2] @ uv_pred_crop[..., None])[..., 0] + tfi[:, :2, 2]          # transform_pts (src/Utils.py:529-536)
+    center_pred = torch.cat([uv_pred, torch.ones((n, 1), dtype=torch.float32)], dim=-1)
+    center_pred = (Kt.inverse() @ center_pred.reshape(n, 3, 1)).reshape(n, 3) * z_pred.reshape(n, 1)
+    trans_delta = center_pred - poseA[..., :3, 3]
   else:
     trans_delta = trans
   if cfg['rot_rep'] == 'axis_angle':
@@ -131,7 +151,8 @@ def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_tensors, me
       A = torch.cat([pd['rgbAs'][b:b + chunk], pd['xyz_mapAs'][b:b + chunk]], dim=1).float()
       Bt = torch.cat([pd['rgbBs'][b:b + chunk], pd['xyz_mapBs'][b:b + chunk]], dim=1).float()
       o = nets.refine_forward(sd, A, Bt, cfg['use_BN'])
-      new_pose, td, rd = pose_update(cfg, pd['poseA'][b:b + chunk], o['trans'], o['rot'], mesh_diameter)
+      new_pose, td, rd = pose_update(cfg, pd['poseA'][b:b + chunk], o['trans'], o['rot'], mesh_diameter,
+                                     tf_to_crops=pd['tf_to_crops'][b:b + chunk], Ks=np.asarray(K, dtype=np.float32))
       outs.append((new_pose, o['trans'], o['rot']))
     if trace is not None:
       trace.append(dict(poseA=pd['poseA'].clone(), trans=torch.cat([o[1] for o in outs]), rot=torch.cat([o[2] for o in outs]),

@@ -97,9 +97,21 @@ static int clip_eval(const clip_tri *T, int i, int j, float *l, float *zp) {
 /* M: B*16 float (row-major clip matrix incl. bbox window transform), pose: B*16 float (ob_in_cam).
  * outputs (each may be NULL): color B*Ho*Wo*3, depth B*Ho*Wo, normal B*Ho*Wo*3, xyz B*Ho*Wo*3,
  * rast B*Ho*Wo*4 = (u, v, z/w, face_id+1) already flipped top-down. */
+/* light_mode 0: light_dir = (0,0,1) (default); 1: light_vec = -light_dir; 2: light_vec = light_pos (light_dir=None);
+ * light_color NULL: the diffuse term takes the surface colour (src/Utils.py:200-211) */
+int oracle_render_lit(const oracle_mesh *m, int B, const float *Mclip, const float *pose, int Ho, int Wo,
+                      int use_light, float w_ambient, float w_diffuse, int light_mode, const float *light_vec, const float *light_color,
+                      float *color, float *depth, float *normal, float *xyz, float *rast);
+
 int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *pose, int Ho, int Wo,
                   int use_light, float w_ambient, float w_diffuse,
                   float *color, float *depth, float *normal, float *xyz, float *rast) {
+  return oracle_render_lit(m, B, Mclip, pose, Ho, Wo, use_light, w_ambient, w_diffuse, 0, 0, 0, color, depth, normal, xyz, rast);
+}
+
+int oracle_render_lit(const oracle_mesh *m, int B, const float *Mclip, const float *pose, int Ho, int Wo,
+                      int use_light, float w_ambient, float w_diffuse, int light_mode, const float *light_vec, const float *light_color,
+                      float *color, float *depth, float *normal, float *xyz, float *rast) {
   const int V = m->V, F = m->F;
   int err = 0;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -129,7 +141,16 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
         nc[v * 3 + r] = fmaf(P[r * 4 + 0], nx, fmaf(P[r * 4 + 1], ny, P[r * 4 + 2] * nz));
       float nn = sqrtf(fmaf(nc[v * 3], nc[v * 3], fmaf(nc[v * 3 + 1], nc[v * 3 + 1], nc[v * 3 + 2] * nc[v * 3 + 2])));
       nn = nn > 1e-12f ? nn : 1e-12f;
-      dv[v] = clampf(-(nc[v * 3 + 2] / nn), 0.f, 1.f);
+      if (light_mode == 0) {
+        dv[v] = clampf(-(nc[v * 3 + 2] / nn), 0.f, 1.f);
+      } else {
+        float L[3];
+        for (int r = 0; r < 3; ++r) L[r] = light_mode == 1 ? light_vec[r] : light_vec[r] - pc[v * 3 + r];
+        float ln = sqrtf(fmaf(L[0], L[0], fmaf(L[1], L[1], L[2] * L[2])));
+        ln = ln > 1e-12f ? ln : 1e-12f;
+        float dt = fmaf(nc[v * 3] / nn, L[0] / ln, fmaf(nc[v * 3 + 1] / nn, L[1] / ln, (nc[v * 3 + 2] / nn) * (L[2] / ln)));
+        dv[v] = clampf(dt, 0.f, 1.f);
+      }
       float w = c[3];
       for (int r = 0; r < 4; ++r) clipc[v * 4 + r] = c[r];
       clipw[v] = w;
@@ -249,7 +270,7 @@ int oracle_render(const oracle_mesh *m, int B, const float *Mclip, const float *
           }
           if (use_light) {
             float d = fmaf(u, dv[i0], fmaf(v, dv[i1], w2 * dv[i2]));
-            for (int c = 0; c < 3; ++c) base[c] = base[c] * w_ambient + (d * base[c]) * w_diffuse;
+            for (int c = 0; c < 3; ++c) base[c] = base[c] * w_ambient + (d * (light_color ? light_color[c] : base[c])) * w_diffuse;
           }
           for (int c = 0; c < 3; ++c) col[c] = clampf(base[c], 0.f, 1.f);
           float nn = sqrtf(fmaf(nrm[0], nrm[0], fmaf(nrm[1], nrm[1], nrm[2] * nrm[2])));

@@ -67,11 +67,11 @@ def clip_matrices(K, H, W, ob_in_cams, bbox2d=None, projection_mat=None):
 
 
 def nvdiffrast_render(K=None, H=None, W=None, ob_in_cams=None, get_normal=False, mesh_tensors=None,
-                      projection_mat=None, bbox2d=None, output_size=None, use_light=False,
-                      w_ambient=0.8, w_diffuse=0.5, extra=None):
+                      projection_mat=None, bbox2d=None, output_size=None, use_light=False, light_color=None,
+                      light_dir=(0, 0, 1), light_pos=(0, 0, 0), w_ambient=0.8, w_diffuse=0.5, extra=None):
   """Returns (color (B,h,w,3), depth (B,h,w), normal_map (B,h,w,3) or None) float32 torch-CPU
   tensors; extra['xyz_map'] (B,h,w,3), extra['rast'] (B,h,w,4) - same contract as the reference
-  (light_dir fixed at its default [0,0,1], light_color=None)."""
+  (src/Utils.py:133-219 incl. the light_dir / light_pos / light_color branches of :200-211)."""
   if extra is None:
     extra = {}
   if output_size is None:
@@ -105,9 +105,19 @@ def nvdiffrast_render(K=None, H=None, W=None, ob_in_cams=None, get_normal=False,
   normal = np.zeros((B, Ho, Wo, 3), np.float32)
   xyz = np.zeros((B, Ho, Wo, 3), np.float32)
   rast = np.zeros((B, Ho, Wo, 4), np.float32)
-  rc = _lib().oracle_render(ctypes.byref(m), ctypes.c_int(B), M.ctypes.data_as(ctypes.c_void_p),
+  if light_dir is not None and np.array_equal(np.asarray(light_dir, dtype=float).reshape(-1), [0, 0, 1]):
+    mode, lvec = 0, np.array([0, 0, -1], np.float32)
+  elif light_dir is not None:
+    mode, lvec = 1, -np.asarray(light_dir, dtype=np.float32).reshape(3)
+  else:
+    mode, lvec = 2, np.asarray(light_pos, dtype=np.float32).reshape(3)
+  lvec = np.ascontiguousarray(lvec)
+  lcol = None if light_color is None else np.ascontiguousarray(np.asarray(light_color, dtype=np.float32).reshape(3))
+  rc = _lib().oracle_render_lit(ctypes.byref(m), ctypes.c_int(B), M.ctypes.data_as(ctypes.c_void_p),
                             pose.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(Ho), ctypes.c_int(Wo),
                             ctypes.c_int(1 if use_light else 0), ctypes.c_float(w_ambient), ctypes.c_float(w_diffuse),
+                            ctypes.c_int(mode), lvec.ctypes.data_as(ctypes.c_void_p),
+                            None if lcol is None else lcol.ctypes.data_as(ctypes.c_void_p),
                             color.ctypes.data_as(ctypes.c_void_p), depth.ctypes.data_as(ctypes.c_void_p),
                             normal.ctypes.data_as(ctypes.c_void_p), xyz.ctypes.data_as(ctypes.c_void_p),
                             rast.ctypes.data_as(ctypes.c_void_p))

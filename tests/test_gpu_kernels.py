@@ -64,6 +64,43 @@ def test_render_crops_match_oracle(sc, fp, textured):
     assert frac <= 2e-4, f'{name}: {frac:.2e} of values differ by > 2e-6 (max {mx:.2e})'
 
 
+@pytest.mark.parametrize('variant', ['light_dir', 'light_pos', 'light_color', 'projection_mat'])
+def test_render_light_and_projection_arguments(sc, fp, variant):
+  """The non-default arguments of nvdiffrast_render (src/Utils.py:159-161: projection_mat; :200-211: light_dir, light_pos with
+  light_dir=None, light_color) against the oracle's restatement of those lines, same tolerance as the default path."""
+  from oracle import geometry as G
+  from oracle.render import nvdiffrast_render as orender
+  from oracle.geometry import projection_matrix_from_intrinsics
+  s = util.scene(0, textured=True) if variant == 'light_color' else sc
+  poses = util.hypotheses(s, 6, jitter_seed=11)
+  tf = G.compute_crop_window_tf_batch(torch.from_numpy(poses), s['K'], 1.2, (160, 160), s['diameter'])
+  bbox = G.crop_bbox2d_ori(tf, (160, 160))
+  kw = dict(use_light=True)
+  if variant == 'light_dir':
+    kw.update(light_dir=np.array([0.3, -0.5, 0.8]))
+  elif variant == 'light_pos':
+    kw.update(light_dir=None, light_pos=np.array([0.4, -0.3, 0.1]))
+  elif variant == 'light_color':
+    kw.update(light_dir=np.array([-0.2, 0.1, 1.0]), light_color=np.array([1.0, 0.6, 0.2]), w_ambient=0.6, w_diffuse=0.7)
+  else:                                 # another near / far pair and a sheared K than the ones the kernel derives itself
+    K2 = s['K'].copy()
+    K2[0, 1] = 3.0
+    kw.update(projection_mat=projection_matrix_from_intrinsics(K2, height=480, width=640, znear=0.05, zfar=20.0))
+  eo, eg = {}, {}
+  co, do, no = orender(K=s['K'], H=480, W=640, ob_in_cams=poses, mesh_tensors=s['mt'], bbox2d=bbox, output_size=(160, 160), get_normal=True,
+                       extra=eo, **kw)
+  cg, dg, ng = fp['U'].nvdiffrast_render(K=s['K'], H=480, W=640, ob_in_cams=torch.from_numpy(poses).cuda(), mesh_tensors=util.to_dev(s['mt']),
+                                         bbox2d=bbox.cuda(), output_size=(160, 160), get_normal=True, extra=eg, **kw)
+  assert float((do > 0).float().mean()) > 0.15
+  assert float(((do > 0) != (dg.cpu() > 0)).float().mean()) <= 1e-4
+  for name, a, b in (('color', co, cg), ('depth', do, dg), ('normal', no, ng), ('xyz', eo['xyz_map'], eg['xyz_map'])):
+    frac, mx, _ = util.mismatch_report(a.numpy(), b.cpu().numpy(), 2e-6)
+    assert frac <= 2e-4, f'{variant} {name}: {frac:.2e} of values differ by > 2e-6 (max {mx:.2e})'
+  # the argument does something: the image differs from the default-light render
+  c0, _, _ = orender(K=s['K'], H=480, W=640, ob_in_cams=poses, mesh_tensors=s['mt'], bbox2d=bbox, output_size=(160, 160), use_light=True)
+  assert float((c0 - co).abs().max()) > 1e-2 or variant == 'projection_mat'
+
+
 def test_render_full_frame_and_edge_cases(sc, fp):
   poses = util.hypotheses(sc, 2)
   poses[1, :3, 3] = [5.0, 5.0, 1.0]      # entirely outside the frustum -> empty image
@@ -266,6 +303,24 @@ def test_pose_update(fp):
       check(lib().fp_pose_update(fp['ctx'].handle, ptr(A_d), ptr(t_d), ptr(r_d), n, rot_dim, 0 if norm_xyz else 1, ptr(tn), cfg['rot_normalizer'],
                                  np.float32(0.191 / 2) if norm_xyz else 1.0, ptr(out), stream_ptr()))
       np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-6)
+  # trans_rep='deepim' (predict_pose_refine.py:201-215): shift of the projected centre inside the crop + depth ratio.  The oracle
+  # inverts tf_to_crops / K with torch.inverse, the kernel by the adjugate: equal to a few float32 roundings of 0.2 .. 1.5 m
+  from oracle import geometry as G
+  K = np.array([[1066.778, 0.7, 312.9869], [0, 1067.487, 241.3109], [0, 0, 1]])
+  A[:, :3, 3] = np.c_[rs.uniform(-0.15, 0.15, n), rs.uniform(-0.1, 0.1, n), rs.uniform(0.4, 1.5, n)]
+  tf = G.compute_crop_window_tf_batch(torch.from_numpy(A), K, 1.2, (160, 160), 0.191)
+  trans = np.c_[rs.randn(n, 2) * 0.05, 1 + rs.randn(n) * 0.03].astype(np.float32)
+  rot = (rs.randn(n, 3) * 0.7).astype(np.float32)
+  for norm_xyz in (False, True):
+    cfg = dict(OP.DEFAULT_REFINE_CFG, trans_rep='deepim', normalize_xyz=norm_xyz)
+    ref, td, _ = OP.pose_update(cfg, torch.from_numpy(A), torch.from_numpy(trans), torch.from_numpy(rot), 0.191, tf_to_crops=tf, Ks=K)
+    assert float(td.abs().max()) > 1e-3
+    out = torch.empty((n, 4, 4), device='cuda')
+    Kd = np.ascontiguousarray(K, dtype=np.float64)
+    A_d, t_d, r_d, tf_d = torch.from_numpy(A).cuda(), torch.from_numpy(trans).cuda(), torch.from_numpy(rot).cuda(), tf.reshape(n, 9).contiguous().cuda()
+    check(lib().fp_pose_update_deepim(fp['ctx'].handle, ptr(A_d), ptr(t_d), ptr(r_d), n, 3, ptr(tf_d), Kd.ctypes.data, 160.0,
+                                      cfg['rot_normalizer'], np.float32(0.191 / 2) if norm_xyz else 1.0, ptr(out), stream_ptr()))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=5e-6)
 
 
 def _pack_conv_weight(w, cin_pad):

@@ -333,7 +333,7 @@ def test_other_frame_size_and_intrinsics(estimators):
   assert pose.shape == (4, 4) and np.isfinite(pose).all()
 
 
-@pytest.mark.parametrize('variant', ['plain_xyz_tanh', '6d_no_bn'])
+@pytest.mark.parametrize('variant', ['plain_xyz_tanh', '6d_no_bn', 'deepim'])
 def test_predictors_other_config_branches(variant):
   """The config branches the released models do not take but the reference implements (predict_pose_refine.py:195-231,
   h5_dataset.py:92-99,151-156): normalize_xyz=False (xyz only centred, translation through tanh * trans_normalizer) and
@@ -353,16 +353,24 @@ def test_predictors_other_config_branches(variant):
     rcfg = dict(REFINE_DEFAULT, normalize_xyz=False)
     scfg = dict(SCORE_DEFAULT, normalize_xyz=False)
     rsd, ssd = S.make_refine_state_dict(0, head_gain=0.1), S.make_score_state_dict(1)      # two chained iterations: low gain
+  elif variant == 'deepim':
+    # trans_rep='deepim' (predict_pose_refine.py:201-215): the head's third output is the depth RATIO, so its bias moves to 1
+    rcfg = dict(REFINE_DEFAULT, trans_rep='deepim', normalize_xyz=False)
+    scfg = dict(SCORE_DEFAULT, normalize_xyz=False)
+    rsd, ssd = S.make_refine_state_dict(0, head_gain=0.1), S.make_score_state_dict(1)
+    rsd['trans_head.1.bias'] = rsd['trans_head.1.bias'] + torch.tensor([0.0, 0.0, 1.0])
   else:
     rcfg = dict(REFINE_DEFAULT, rot_rep='6d', use_BN=False)
     scfg = dict(SCORE_DEFAULT, use_BN=False)
     rsd, ssd = S.make_refine_state_dict(seed=2, use_bn=False, rot_out_dim=6), S.make_score_state_dict(seed=3, use_bn=False)
   refiner = PoseRefinePredictor(state_dict=rsd, cfg=rcfg)
   got, _ = refiner.predict(sc['rgb'], depth, sc['K'], poses, xyz_map, mesh_tensors=mt, mesh_diameter=sc['diameter'], iteration=2)
-  ocfg = dict(OP.DEFAULT_REFINE_CFG, **{k: rcfg[k] for k in ('normalize_xyz', 'rot_rep', 'use_BN')})
+  ocfg = dict(OP.DEFAULT_REFINE_CFG, **{k: rcfg[k] for k in ('normalize_xyz', 'rot_rep', 'use_BN', 'trans_rep')})
   ref = OP.refine_predict(ocfg, rsd, sc['rgb'], depth, sc['K'], poses, xyz_map, sc['mt'], sc['diameter'], iteration=2, chunk=8)
   assert float((torch.as_tensor(poses) - ref).abs().max()) > 1e-3          # the networks moved the poses
   np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=1e-3)
+  if variant == 'deepim':
+    return                  # trans_rep only exists in the refiner; the scorer's normalize_xyz=False branch is the first variant's
   scorer = ScorePredictor(state_dict=ssd, cfg=scfg)
   s_got, _ = scorer.predict(sc['rgb'], depth, sc['K'], ref.numpy(), mesh_tensors=mt, mesh_diameter=sc['diameter'])
   oscfg = dict(OP.DEFAULT_SCORE_CFG, **{k: scfg[k] for k in ('normalize_xyz', 'use_BN')})

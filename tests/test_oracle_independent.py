@@ -118,6 +118,49 @@ def test_rasteriser_against_float64_point_in_triangle_and_plane_depth():
   assert c.min() >= -1e-6 and c.max() <= 1 + 1e-6 and np.abs(c.sum(1) - 1).max() < 1.0 + 1e-6   # convex blends of the vertex colours
 
 
+def test_rasteriser_light_arguments_against_the_analytic_lambert_term():
+  """light_dir / light_pos / light_color (src/Utils.py:200-211) on a fronto-parallel quad with one normal: the diffuse term is
+  clip(n . normalize(-light_dir), 0, 1) everywhere (directional) or n . normalize(light_pos - p) at the pixel's surface point
+  (point light; per-vertex then interpolated - on a small quad the two differ by less than 1e-3), colour = c w_a + d lc w_d."""
+  from oracle.render import nvdiffrast_render
+  K = np.array([[500.0, 0, 80.3], [0, 480.0, 59.6], [0, 0, 1]])
+  H, W, z = 120, 160, 0.8
+  quad = np.array([[-0.02, -0.02, 0], [0.02, -0.02, 0], [0.02, 0.02, 0], [-0.02, 0.02, 0]], np.float32)
+  base = np.array([0.8, 0.5, 0.3], np.float32)
+  mt = dict(pos=torch.from_numpy(quad), faces=torch.tensor([[0, 1, 2], [0, 2, 3]], dtype=torch.int32),
+            vnormals=torch.tensor([[0, 0, -1.0]] * 4), vertex_color=torch.from_numpy(np.tile(base, (4, 1))))
+  pose = np.eye(4, dtype=np.float32)
+  pose[:3, 3] = [0, 0, z]
+  n = np.array([0, 0, -1.0])
+
+  def run(**kw):
+    extra = {}
+    c, d, _ = nvdiffrast_render(K=K, H=H, W=W, ob_in_cams=pose[None], mesh_tensors=mt, use_light=True, extra=extra, **kw)
+    cov = d[0].numpy() > 0
+    assert cov.sum() > 400
+    return c[0].numpy()[cov], extra['xyz_map'][0].numpy()[cov]
+
+  ld = np.array([0.3, -0.5, 0.8])
+  c, _ = run(light_dir=ld)
+  dterm = np.clip(n @ (-ld / np.linalg.norm(ld)), 0, 1)
+  np.testing.assert_allclose(c, np.tile(base * 0.8 + dterm * base * 0.5, (len(c), 1)), atol=2e-6)
+  c, _ = run(light_dir=ld, light_color=np.array([1.0, 0.6, 0.2]), w_ambient=0.6, w_diffuse=0.7)
+  np.testing.assert_allclose(c, np.tile(np.clip(base * 0.6 + dterm * np.array([1.0, 0.6, 0.2]) * 0.7, 0, 1), (len(c), 1)), atol=2e-6)
+  lp = np.array([0.4, -0.3, 0.1])
+  c, xyz = run(light_dir=None, light_pos=lp)
+  L = lp[None] - xyz.astype(np.float64)
+  dpix = np.clip((L / np.linalg.norm(L, axis=1, keepdims=True)) @ n, 0, 1)
+  np.testing.assert_allclose(c, base[None] * 0.8 + dpix[:, None] * base[None] * 0.5, atol=1e-3)
+  c0, _ = run()                                            # the default is light_dir = (0,0,1): n . (0,0,-1) = 1
+  np.testing.assert_allclose(c0, np.tile(np.clip(base * 0.8 + base * 0.5, 0, 1), (len(c0), 1)), atol=2e-6)
+  # projection_mat: the matrix the kernel derives itself gives the same image as passing it explicitly
+  from oracle.geometry import projection_matrix_from_intrinsics
+  a = nvdiffrast_render(K=K, H=H, W=W, ob_in_cams=pose[None], mesh_tensors=mt, use_light=True)[0]
+  b = nvdiffrast_render(K=None, H=H, W=W, ob_in_cams=pose[None], mesh_tensors=mt, use_light=True,
+                        projection_mat=projection_matrix_from_intrinsics(K, height=H, width=W, znear=0.001, zfar=100))[0]
+  assert torch.equal(a, b)
+
+
 def test_rasteriser_triangles_through_the_camera_plane_against_the_analytic_plane():
   """A ground plane (two triangles) that runs from 1 m BEHIND the camera to 3 m in front of it: every triangle has a vertex with
   w <= 0, so the whole image comes from the homogeneous path of oracle/raster_c.c (nvdiffrast would clip against the near plane).
