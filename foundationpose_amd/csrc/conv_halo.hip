@@ -831,9 +831,9 @@ void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
   *n_tail4 = 0;
   if (!g_halo_tail || rem == 0) return;
   if (n_tiles < slots) {
-    // less than one round (tracking: 1 .. 64 hypotheses): the launch lasts as long as ONE workgroup, so quarter tiles
-    // (4 x the workgroups, ~0.35 x the time each) win as long as they still fit one round
-    if (4 * n_tiles <= slots) {
+    // less than one round (tracking; a rank's shard of an 8-way job: 32 hypotheses = 100 tiles at C = 512): the launch lasts as
+    // long as ONE workgroup, so quarter tiles (4 x the workgroups, ~0.35 x the time each) win as long as they fit two rounds
+    if (4 * n_tiles <= 2 * slots) {
       *n_main = 0;
       *n_tail4 = 4 * n_tiles;
     }

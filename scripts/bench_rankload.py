@@ -29,9 +29,9 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
     ctx = est.refiner.ctx
-    ctx.prof_reset(); ctx.prof_enable(True)
+    ctx.prof_reset(); ctx.prof_enable(2)
     step(); torch.cuda.synchronize()
-    ctx.prof_enable(False)
+    ctx.prof_enable(0)
     cls = {c: ctx.prof_read(c) for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'render')}
     print('   per-class ms (HIP events; overlapping launches on side streams each count their own span): '
           + '  '.join(f"{c} {v['total_ms']:.2f}/{v['launches']}" for c, v in cls.items()))
@@ -47,6 +47,12 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     n = -(-bench.N_HYP // W)
+    ctx = est.refiner.ctx
+    ctx.prof_reset(); ctx.prof_enable(2)
+    one(); torch.cuda.synchronize()
+    ctx.prof_enable(0)
+    cls = {c: ctx.prof_read(c) for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'heads_wall', 'render')}
+    print('   per-class ms: ' + '  '.join(f"{c} {v['total_ms']:.2f}/{v['launches']}" for c, v in cls.items()))
     print(f'world {W}: {n} hypotheses on this rank: {dt * 1e3:.2f} ms/step local -> at most {bench.N_HYP / dt:.0f} hyp/s for the job '
           f'(x{(bench.N_HYP / dt) / 1.0:.0f}); per-hypothesis cost x{dt / n / 1.0 * 1e3:.3f} ms')
 
