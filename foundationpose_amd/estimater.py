@@ -147,8 +147,14 @@ class FoundationPose:
       return sharded_refine_and_score(self, K, rgb, depth, xyz_map, hyp, iteration)
     shared = dict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K, glctx=self.glctx,
                   mesh_diameter=self.diameter, get_vis=self.debug >= 2)
-    refined, _ = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
-    scores, _ = self.scorer.predict(ob_in_cams=refined, normal_map=None, **shared)
+    refined, vis = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
+    if vis is not None:                  # src/estimater.py:216-217 (debug >= 2)
+      from .vis import write_png
+      write_png(f'{self.debug_dir}/vis_refiner.png', vis)
+    scores, vis = self.scorer.predict(ob_in_cams=refined, normal_map=None, **shared)
+    if vis is not None:                  # src/estimater.py:220-221
+      from .vis import write_png
+      write_png(f'{self.debug_dir}/vis_score.png', vis)
     return refined, scores
 
   def register(self, K, rgb, depth, ob_mask, ob_id=None, glctx=None, iteration=5):
@@ -244,9 +250,14 @@ class FoundationPose:
     if self.pose_last is None:
       logging.info("Please init pose by register first")
       raise RuntimeError
+    pose_in = self.pose_last
     pose, _, _, _ = self._run_frame(rgb, depth, K, iteration, 1, None)
-    if self.debug >= 2:
-      extra['vis'] = None          # the debug canvas is outside the hot path
+    if self.debug >= 2:            # src/estimater.py:263-266: the refiner's canvas for this frame (debug only: the frame is refined a second time for it)
+      d = U.bilateral_filter_depth(U.erode_depth(torch.as_tensor(depth, device='cuda', dtype=torch.float), radius=2, device='cuda'), radius=2, device='cuda')
+      xyz_map = U.depth2xyzmap_batch(d[None], np.asarray(K, dtype=np.float32)[None], zfar=np.inf)[0]
+      _, extra['vis'] = self.refiner.predict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=d, K=K, glctx=self.glctx,
+                                             mesh_diameter=self.diameter, ob_in_cams=pose_in.reshape(-1, 4, 4), normal_map=None, xyz_map=xyz_map,
+                                             iteration=iteration, get_vis=True)
     self.pose_last = pose
     return (pose @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)
 

@@ -201,5 +201,11 @@ class PoseRefinePredictor:
     self.last_trans_update = trans
     self.last_rot_update = rot
     if get_vis:
-      logging.info("get_vis: the debug canvas (cv2/torchvision drawing) is outside the hot path; returning None")
+      # predict_pose_refine.py:241-293: crops at the start poses and at the refined ones, side by side (vis.py: no cv2 here, so no text labels)
+      from .vis import refine_canvas
+      logging.info("get_vis...")
+      kw = dict(mesh_diameter=mesh_diameter, cfg=self.cfg, glctx=glctx, mesh_tensors=mesh_tensors)
+      before = make_crop_data_batch(self.cfg['input_resize'], ob_in_cams, mesh, rgb, depth, K, self.cfg['crop_ratio'], xyz_map, **kw)
+      after = make_crop_data_batch(self.cfg['input_resize'], poses, mesh, rgb, depth, K, self.cfg['crop_ratio'], xyz_map, **kw)
+      return poses, refine_canvas(before, after)
     return poses, None

@@ -148,5 +148,11 @@ class ScorePredictor:
     scores = logits.reshape(-1) + 100
     logging.info('forward done')
     if get_vis:
-      logging.info("get_vis: the debug canvas is outside the hot path; returning None")
+      # predict_score.py:219-224: one row per hypothesis, best first (vis.py: no cv2 here, so no text labels)
+      from .vis import score_canvas
+      logging.info("get_vis...")
+      pd = make_crop_data_batch(self.cfg['input_resize'], ob_in_cams, mesh, rgb, depth, K, self.cfg['crop_ratio'], mesh_diameter=mesh_diameter,
+                                glctx=glctx, mesh_tensors=mesh_tensors, cfg=self.cfg)
+      ids = scores.argsort(descending=True)
+      return scores, score_canvas(pd, ids.cpu().numpy(), scores.cpu().numpy())
     return scores, None

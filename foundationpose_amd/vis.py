@@ -1,0 +1,123 @@
+"""Debug canvases of `get_vis=True` (predict_pose_refine.py:241-293, predict_score.py:27-52,219-224; src/Utils.py:293-300,456-478).
+
+Outside the hot path and host-side only.  The reference draws them with cv2 (JET colour map, `resize`, `putText`) and torchvision's
+`make_grid`; neither is in this image, so the layout is rebuilt with numpy / torch and two things differ, on purpose and visibly
+documented here: the JET map is the analytic one (clip(1.5 - |4x - k|), OpenCV's LUT differs by at most a few grey levels) and no text
+labels are drawn (`id:..`, `score:..`).  Rows are in the same order, so row i of the scorer's canvas is the i-th best hypothesis."""
+import numpy as np
+import torch
+
+
+def _jet(v_u8):
+  """uint8 (H,W) -> RGB uint8 (H,W,3): analytic JET (blue -> cyan -> yellow -> red)."""
+  x = v_u8.astype(np.float32) / 255.0
+  r = np.clip(1.5 - np.abs(4 * x - 3), 0, 1)
+  g = np.clip(1.5 - np.abs(4 * x - 2), 0, 1)
+  b = np.clip(1.5 - np.abs(4 * x - 1), 0, 1)
+  return (np.stack([r, g, b], -1) * 255).astype(np.uint8)
+
+
+def depth_to_vis(depth, zmin=None, zmax=None, mode='rgb', inverse=True):
+  """src/Utils.py:456-478."""
+  depth = np.asarray(depth, dtype=np.float32)
+  if zmin is None:
+    zmin = depth.min()
+  if zmax is None:
+    zmax = depth.max()
+  if inverse:
+    invalid = depth < 0.001
+    vis = zmin / (depth + 1e-8)
+    vis[invalid] = 0
+  else:
+    depth = depth.clip(zmin, zmax)
+    invalid = (depth == zmin) | (depth == zmax)
+    with np.errstate(divide='ignore', invalid='ignore'):
+      vis = (depth - zmin) / (zmax - zmin)
+    vis[invalid] = 1
+  if mode == 'gray':
+    return (vis * 255).clip(0, 255).astype(np.uint8)
+  if mode == 'rgb':
+    return _jet((np.nan_to_num(vis) * 255).astype(np.uint8))
+  raise RuntimeError
+
+
+def make_grid_image(imgs, nrow, padding=5, pad_value=255):
+  """src/Utils.py:293-300 = torchvision.utils.make_grid on (B,H,W,C) images: `nrow` images per row, `padding` pixels of
+  `pad_value` around and between them; returns uint8 (H',W',C)."""
+  imgs = [np.asarray(im).astype(np.uint8) for im in imgs]          # (the reference truncates to uint8 after the grid: same values)
+  B = len(imgs)
+  H, W, C = imgs[0].shape
+  if B == 1:
+    return imgs[0]                                     # make_grid returns a single image unpadded
+  xmaps = min(nrow, B)
+  ymaps = int(np.ceil(B / xmaps))
+  h, w = H + padding, W + padding
+  grid = np.full((h * ymaps + padding, w * xmaps + padding, C), pad_value, dtype=np.uint8)
+  for k in range(B):
+    y, x = divmod(k, xmaps)
+    grid[y * h + padding:y * h + padding + H, x * w + padding:x * w + padding + W] = imgs[k]
+  return grid
+
+
+def write_png(path, img):
+  """uint8 (H,W,3) -> an 8-bit RGB PNG (what imageio.imwrite does for the debug canvases, src/estimater.py:217,221); zlib only."""
+  import struct
+  import zlib
+  img = np.ascontiguousarray(img, dtype=np.uint8)
+  H, W, _ = img.shape
+  raw = np.concatenate([np.zeros((H, 1), np.uint8), img.reshape(H, W * 3)], axis=1).tobytes()       # filter type 0 per scanline
+
+  def chunk(tag, data):
+    body = tag + data
+    return struct.pack('>I', len(data)) + body + struct.pack('>I', zlib.crc32(body) & 0xffffffff)
+  with open(path, 'wb') as f:
+    f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, 2, 0, 0, 0)) + chunk(b'IDAT', zlib.compress(raw, 6)) +
+            chunk(b'IEND', b''))
+
+
+def _row_images(pose_data, i):
+  rgbA = (pose_data.rgbAs[i] * 255).permute(1, 2, 0).data.cpu().numpy()
+  rgbB = (pose_data.rgbBs[i] * 255).permute(1, 2, 0).data.cpu().numpy()
+  H, W = rgbA.shape[:2]
+  if pose_data.depthAs is not None:
+    dA = pose_data.depthAs[i].data.cpu().numpy().reshape(H, W)
+    dB = pose_data.depthBs[i].data.cpu().numpy().reshape(H, W)
+  else:
+    dA = pose_data.xyz_mapAs[i][2].data.cpu().numpy().reshape(H, W)
+    dB = pose_data.xyz_mapBs[i][2].data.cpu().numpy().reshape(H, W)
+  return rgbA, rgbB, dA, dB
+
+
+def refine_canvas(pose_data_before, pose_data_after, padding=2):
+  """predict_pose_refine.py:241-293: per hypothesis a row (render, observed crop, render depth, observed depth; the depths share one
+  colour range), all rows stacked, the start poses on the left and the refined poses on the right."""
+  halves = []
+  for pd in (pose_data_before, pose_data_after):
+    rows = []
+    for i in range(len(pd.rgbAs)):
+      rgbA, rgbB, dA, dB = _row_images(pd, i)
+      zmin, zmax = min(dA.min(), dB.min()), max(dA.max(), dB.max())
+      row = [rgbA, rgbB, depth_to_vis(dA, zmin=zmin, zmax=zmax, inverse=False), depth_to_vis(dB, zmin=zmin, zmax=zmax, inverse=False)]
+      rows.append(make_grid_image(row, nrow=len(row), padding=padding, pad_value=255))
+    halves.append(make_grid_image(rows, nrow=1, padding=padding, pad_value=255))
+  return make_grid_image(halves, nrow=2, padding=padding, pad_value=255)
+
+
+def score_canvas(pose_data, ids, scores, pad_margin=5):
+  """predict_score.py:27-52: hypotheses in the order `ids` (best first), each a row render | render depth | observed crop | observed
+  depth, scaled to 100 pixels of height (bilinear), 5-pixel white separators."""
+  assert len(scores) == len(ids)
+  canvas = []
+  for i in [int(x) for x in ids]:
+    rgbA, rgbB, dA, dB = _row_images(pose_data, i)
+    zmin, zmax = dA.min(), dA.max()
+    pad = np.ones((rgbA.shape[0], pad_margin, 3)) * 255
+    row = np.concatenate([rgbA, pad, depth_to_vis(dA, zmin=zmin, zmax=zmax, inverse=False), pad, rgbB, pad,
+                          depth_to_vis(dB, zmin=zmin, zmax=zmax, inverse=False)], axis=1)
+    s = 100 / row.shape[0]
+    t = torch.from_numpy(np.ascontiguousarray(row, dtype=np.float32)).permute(2, 0, 1)[None]
+    t = torch.nn.functional.interpolate(t, size=(int(round(row.shape[0] * s)), int(round(row.shape[1] * s))), mode='bilinear', align_corners=False)
+    row = t[0].permute(1, 2, 0).numpy()
+    canvas.append(row)
+    canvas.append(np.ones((pad_margin, row.shape[1], 3)) * 255)
+  return np.concatenate(canvas, axis=0).astype(np.uint8)
