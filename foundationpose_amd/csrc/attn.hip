@@ -29,29 +29,6 @@ __device__ __forceinline__ void at_glds16(const f16 *g, f16 *l) {
   asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory");
 }
 
-// The transposed V image [b][4][128][416] is padded from 400 to 416 tokens; the V projection writes tokens < T only, the
-// pad must read as zero (P^T carries exact zeros there, but 0 x NaN from stale arena bytes would poison O).  Zeroing just
-// the pad columns replaces a memset of the whole 107-MB image per attention call.
-__global__ void vt_pad_zero_kernel(f16 *__restrict__ vt, int rows, int T) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  f16 *row = vt + (size_t)r * AT_TP;
-  if (T == 400) {                               // the network's case: 16 pad columns = two aligned 16-byte stores per row
-    *reinterpret_cast<uint4 *>(row + 400) = make_uint4(0, 0, 0, 0);
-    *reinterpret_cast<uint4 *>(row + 408) = make_uint4(0, 0, 0, 0);
-    return;
-  }
-  for (int t = T; t < AT_TP; ++t) row[vt_col(t)] = (f16)0.f;
-}
-
-int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s) {
-  const int rows = B * 4 * AT_DH;
-  if (rows == 0 || T >= AT_TP) return FP_OK;
-  hipLaunchKernelGGL(vt_pad_zero_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, vt, rows, T);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
 // Flash-style multi-head self-attention core (400 tokens, 4 heads x 128) on v_mfma_f32_32x32x16_f16.
 // One workgroup = one (hypothesis, head, 224-query block): 13 query tiles of 32 split 7 + 6 over two workgroups;
 // each of the 7 waves owns 32 queries and keeps Q^T (32 regs), the running max / sum and O^T (4 x 32x32

@@ -245,7 +245,6 @@ int launch_tok_gemm(fp_ctx *ctx, const TokGemmArgs &a, int epi, hipStream_t s);
 // Sum of `nparts` consecutive partial rows per hypothesis (fixed order) / T, gamma, beta, Linear(512 -> out_dim)
 int launch_mean_head(const float *partial, int nparts, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
                      int out_dim, float *out, hipStream_t s);
-int launch_vt_pad_zero(f16 *vt, int B, int T, hipStream_t s);
 int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
 int launch_layernorm_h(const f16 *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
 int launch_ln_mean_head_h(const f16 *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,

@@ -413,7 +413,6 @@ int run_qkv(fp_ctx *ctx, const LinP *const *q, const LinP *const *k, const LinP 
   FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_ROWS, s));
   a.nblk = n_layers;
   for (int l = 0; l < n_layers; ++l) {
-    FP_TRY(launch_vt_pad_zero(vt[l], N, 400, s));
     a.blk[l] = TokGemmBlock{v[l]->w, v[l]->bias, vt[l], 0, 0, 0};
   }
   return launch_tok_gemm(ctx, a, TG_EPI_VT, s);
@@ -529,7 +528,6 @@ extern "C" int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const f
     a.gamma = h_gamma ? d_g : nullptr;
     a.beta = h_beta ? d_b : nullptr;
     a.gsum = (float *)d_out;
-    if (epilogue == TG_EPI_VT) FP_TRY(launch_vt_pad_zero((f16 *)d_out, tokens > 0 ? M / tokens : 0, tokens, (hipStream_t)stream));
     FP_TRY(launch_tok_gemm(ctx, a, epilogue, (hipStream_t)stream));
     FP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return FP_OK;

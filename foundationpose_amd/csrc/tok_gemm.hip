@@ -204,7 +204,12 @@ __global__ __launch_bounds__(TG_THREADS, 2) void tok_gemm_kernel(TokGemmArgs p) 
       if (m < p.M) {
         const int b = m / p.tokens, t = m - b * p.tokens;
         const int col = blk.coff + wave * 128 + c, h = col >> 7, d = col & 127;
-        *reinterpret_cast<uint4 *>(img + (((size_t)b * 4 + h) * 128 + d) * 416 + (t & ~15) + (ch8 & 1) * 8) = v;
+        f16 *row = img + (((size_t)b * 4 + h) * 128 + d) * 416;
+        *reinterpret_cast<uint4 *>(row + (t & ~15) + (ch8 & 1) * 8) = v;
+        // the image is 416 tokens wide: the lanes that store a hypothesis' last 16 tokens also zero the columns behind them
+        // (the attention kernel reads whole 64-key blocks; was a launch of its own)
+        if ((t & ~15) + 16 == p.tokens)
+          for (int z = p.tokens; z < 416; z += 16) *reinterpret_cast<uint4 *>(row + z + (ch8 & 1) * 8) = uint4{0u, 0u, 0u, 0u};
       }
     }
     TSTAMP(3);
