@@ -595,25 +595,45 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const float *__res
   // float64 scores / softmax / weighted sum (see small_linear_kernel): with the q/k gain of the seeded scorer the scores are
   // O(100) with hypothesis-specific parts of O(1); in fp32 their rounding alone moves the logits by several 1e-6
   __shared__ double sc[4][CA_MAXL];
+  __shared__ double qs[4][128];
   const int i = blockIdx.x, grp = blockIdx.y, hd = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float *base = qkv + (size_t)grp * L * 1536;
   const float *qr = base + (size_t)i * 1536 + hd * 128;
-  const double q0 = qr[lane * 2], q1 = qr[lane * 2 + 1];
+  qs[hd][lane * 2] = qr[lane * 2];
+  qs[hd][lane * 2 + 1] = qr[lane * 2 + 1];
+  __syncthreads();
   const double scale = 0.08838834764831845;
   double mx = -1.0e300;
-  for (int j0 = 0; j0 < L; j0 += 8) {               // eight key rows in flight (a rolled loop waits for each row's load in turn)
-    float2 kv[8];
+  // scores: a lane owns keys lane, lane + 64, ... and adds the 128 products of each in index order itself (a wave-wide reduction per
+  // key - 12 cross-lane double adds for 2 products per lane - was most of this kernel: 104 -> 73 us at L = 252); four keys in flight per lane
+  for (int j0 = lane; j0 < L; j0 += 256) {
+    const float4 *kr[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) kv[u] = *reinterpret_cast<const float2 *>(base + (size_t)min(j0 + u, L - 1) * 1536 + 512 + hd * 128 + lane * 2);
+    for (int u = 0; u < 4; ++u) kr[u] = reinterpret_cast<const float4 *>(base + (size_t)min(j0 + 64 * u, L - 1) * 1536 + 512 + hd * 128);
+    for (int d4 = 0; d4 < 32; ++d4) {
+      float4 kv[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const double s = wave_sum_d(q0 * (double)kv[u].x + q1 * (double)kv[u].y) * scale;
-      if (j0 + u < L) {
-        if (lane == 0) sc[hd][j0 + u] = s;
-        mx = fmax(mx, s);
+      for (int u = 0; u < 4; ++u) kv[u] = kr[u][d4];
+      const double qa = qs[hd][4 * d4], qb = qs[hd][4 * d4 + 1], qc = qs[hd][4 * d4 + 2], qd = qs[hd][4 * d4 + 3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[u] += qa * (double)kv[u].x;
+        acc[u] += qb * (double)kv[u].y;
+        acc[u] += qc * (double)kv[u].z;
+        acc[u] += qd * (double)kv[u].w;
       }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j0 + 64 * u < L) {
+        const double sv = acc[u] * scale;
+        sc[hd][j0 + 64 * u] = sv;
+        mx = fmax(mx, sv);
+      }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   double sum = 0.0;
