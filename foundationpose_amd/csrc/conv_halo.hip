@@ -726,17 +726,314 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
   })
 }
 
+#ifdef HALO_STAMP
+// ------------------------------------------------------------------------------------------------------------------------
+// PERSISTENT FORM of the 8-wave tile for launches of two or more full rounds (diagnostic builds only, FP_HALO_PERSIST=1: measured
+// equal to the per-tile form inside a step - DESIGN.md section 6 - and kept as the record of that experiment; bit-identical results): one workgroup per CU walks `rounds` 512-pixel
+// tiles (tile r of workgroup w is logical tile r * n_wg + xcd_remap(w)), and the group stream never stops at a tile boundary:
+//   * the band of the next tile's chunk 0 is requested in the last chunk's ky = 0 group, its first weight group in the last
+//     ky = 2 group - exactly where the next chunk's / next group's DMAs go inside a tile - so a tile has NO prologue;
+//   * the epilogue needs one barrier and no buffer of its own: each wave stages its 128 pixels x 64 channels through a slice of
+//     the band buffer the last chunk has just released (residual rows in, fp32 add / ReLU as in the staged epilogue, rows out:
+//     16-byte loads and stores of 128 contiguous bytes per pixel), and its stores drain under the next tile's first group (a
+//     counted vmcnt leaves them in flight: loads, stores and LDS-DMA retire in issue order).  A first form that stored 8 bytes
+//     per (pixel, 4 channels) straight from the accumulators - 32 cache lines per instruction - was 18 % SLOWER than the
+//     per-tile kernel (375 against 317 us at C = 128) while the same loop without any epilogue traffic ran 234 us.
+// The arithmetic of an output element is that of halo_tile_dma: results are bit-identical.
 template <int W, bool RES, bool POST>
-__global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, int n_main) {
+__device__ __forceinline__ void halo_persist(const ConvArgs &p, const int n_wg, const int rounds, f16 *lds) {
+  constexpr int NT = 4, NPW = 4, TM = 512;
+  using C = HaloCfgD<W, TM>;
+  constexpr int H = W;
+  constexpr int PXW = 32 * NT;
+  constexpr int HQ = C::HQ;
+  constexpr int WQ = 24 / (2 * NPW);
+  constexpr int NST = NT * 4;           // epilogue stores per wave and tile
+  f16 *wbuf = lds + C::WBUF_OFF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NPW, wn = wave % NPW;
+  const int lr = lane & 31, lh = lane >> 5;
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  const int total_rows = p.Nimg * H;
+  const int nchunk = p.Cin / HL_CK;
+  const int n_ct = p.Cout / HL_BM;
+  const int wslot = xcd_remap(blockIdx.x, n_wg);
+  const int hpix_max = total_rows * W - 1;
+
+  int wa[2];
+  {
+    const int co = wm * 64 + lr;
+    wa[0] = co * 32 + ((lh ^ ((co >> 2) & 3)) * 8);
+    wa[1] = co * 32 + (((2 + lh) ^ ((co >> 2) & 3)) * 8);
+  }
+  auto halo_dma = [&](int gr0, int cc, int hb, auto hc) __attribute__((always_inline)) {
+    constexpr int h = decltype(hc)::value;
+    int l4 = lane >> 2;
+    asm volatile("" : "+v"(l4));
+    const int P = (h * 8 + wave) * 16 + l4;
+    const int c = (lane & 3) ^ ((P >> 2) & 3);
+    const int gp = min(max(gr0 * W + P - 1, 0), hpix_max);
+    const unsigned off = (unsigned)(gp * p.Cin + cc * HL_CK + c * 8) * 2u;
+    glds16(p.in, off, lds + hb * C::HBUF_HALFS + (h * 8 + wave) * 512);
+  };
+  const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
+  auto wstage = [&](int c0w, int cc, int ky, int buf, auto q0c, auto q1c) __attribute__((always_inline)) {
+    constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
+#pragma unroll
+    for (int q = Q0; q < Q1; ++q) {
+      const int g0 = q * 2 * NPW;
+      const f16 *sb = p.w + (size_t)(c0w + (g0 & 7) * 16) * p.Kpad + (ky * 3 + (g0 >> 3)) * p.Cin + cc * HL_CK;
+      glds16(sb, woff, wbuf + buf * C::WBUF_HALFS + (q * 2 * NPW + wave) * 512);
+    }
+  };
+  auto tile_of = [&](int r, int *m0, int *c0) __attribute__((always_inline)) {
+    const int L = r * n_wg + wslot;
+    *m0 = (L / n_ct) * TM;
+    *c0 = (L % n_ct) * HL_BM;
+  };
+
+  if (tid < 1) *reinterpret_cast<u32x4 *>(&lds[C::ZERO_OFF]) = u32x4{0, 0, 0, 0};
+  int m0, c0;
+  tile_of(0, &m0, &c0);
+  {
+    const int gr0 = m0 / W - 1;
+    auto all = [&](auto hc) __attribute__((always_inline)) {
+      if constexpr (decltype(hc)::value < HQ) halo_dma(gr0, 0, 0, hc);
+    };
+    all(IC<0>{}), all(IC<1>{}), all(IC<2>{}), all(IC<3>{}), all(IC<4>{}), all(IC<5>{}), all(IC<6>{}), all(IC<7>{});
+  }
+  wstage(c0, 0, 0, 0, IC<0>{}, IC<WQ>{});
+  int g = 0;
+  bool prev_full = false;               // the previous tile of this workgroup issued exactly NST stores per wave
+
+  for (int r = 0; r < rounds; ++r) {
+    const int GR0 = m0 / W - 1;
+    const bool has_next = r + 1 < rounds;
+    int m0n = 0, c0n = 0;
+    if (has_next) tile_of(r + 1, &m0n, &c0n);
+    const int GR0n = m0n / W - 1;
+    // ---- per-tile lane constants (as in halo_tile_dma) ----
+    const int pb = m0 + wn * PXW + lr - GR0 * W - W;
+    unsigned vmp[(NT + 2) / 3];
+#pragma unroll
+    for (int t = 0; t < (NT + 2) / 3; ++t) vmp[t] = 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int m = min(m0 + wn * PXW + j * 32 + lr, p.M - 1);
+      const int gr = m / W, ox = m - gr * W, oy = gr % H;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = oy + ky - 1, ix = ox + kx - 1;
+          if (iy >= 0 && iy < H && ix >= 0 && ix < W) vmp[j / 3] |= 1u << ((j % 3) * 9 + ky * 3 + kx);
+        }
+    }
+    floatx16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j][rg * 4 + 0] = bv.x;
+          acc[i][j][rg * 4 + 1] = bv.y;
+          acc[i][j][rg * 4 + 2] = bv.z;
+          acc[i][j][rg * 4 + 3] = bv.w;
+        }
+      }
+
+    for (int cc = 0; cc < nchunk; ++cc) {
+      const f16 *halo = lds + (cc & 1) * C::HBUF_HALFS;
+      const bool band_next = (cc + 1 < nchunk) || has_next;      // a band is requested in this chunk's ky = 0 group
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky, ++g) {
+        const int buf = g & 1;
+        // weights(g) - and at ky = 0 the band of this chunk - must have landed.  Younger operations that may stay in flight:
+        // at ky = 1 the HQ band DMAs requested one group ago; at the first group of a tile the NST stores of the previous
+        // tile's epilogue (issued after this group's weights and band were requested).
+        if (ky == 1 && band_next) {
+          static_assert(HQ >= 2 && HQ <= 6, "add the vmcnt immediate for this tile");
+          if constexpr (HQ == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+          else if constexpr (HQ == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+          else if constexpr (HQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+          else if constexpr (HQ == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        } else if (ky == 0 && cc == 0 && prev_full) {
+          // behind this group's band and weight requests the previous epilogue issued its residual loads (consumed, so
+          // complete) and then NST stores: the stores may stay in flight
+          static_assert(NST == 16, "the immediates below");
+          asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        int ncc = cc, nky = ky + 1, c0w = c0;
+        bool more_w = true;
+        if (nky == 3) {
+          nky = 0;
+          ncc = cc + 1;
+          if (ncc == nchunk) {          // the next group is the first one of the next tile
+            ncc = 0;
+            c0w = c0n;
+            more_w = has_next;
+          }
+        }
+        const bool more_h = (ky == 0) && band_next;
+        const int hcc = cc + 1 < nchunk ? cc + 1 : 0, hgr0 = cc + 1 < nchunk ? GR0 : GR0n;
+        const f16 *wb = wbuf + buf * C::WBUF_HALFS;
+        unsigned vm[(NT + 2) / 3];
+#pragma unroll
+        for (int t = 0; t < (NT + 2) / 3; ++t) {
+          vm[t] = vmp[t];
+          asm volatile("" : "+v"(vm[t]));
+        }
+        constexpr int NV = 6 * NT, BD = 4;
+        half8 af[2][2], bf[BD];
+        int tapb[3][2];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int Pt = pb + ky * W + kx, sw = (Pt >> 2) & 3;
+          tapb[kx][0] = Pt * 32 + ((lh ^ sw) * 8);
+          tapb[kx][1] = Pt * 32 + (((2 + lh) ^ sw) * 8);
+        }
+        auto load_a = [&](int st, int set) __attribute__((always_inline)) {
+          const int kx = st >> 1, ks = st & 1;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const half8 *>(&wb[wa[ks] + i * (32 * 32) + kx * (HL_BM * HL_CK)]);
+        };
+        auto load_b = [&](auto tc) __attribute__((always_inline)) {
+          constexpr int t = decltype(tc)::value, st = t / NT, j = t % NT, kx = st >> 1, ks = st & 1;
+          constexpr int imm = j * 32 * 32;
+          const bool ok = (vm[j / 3] >> ((j % 3) * 9 + ky * 3 + kx)) & 1u;
+          const int base = ok ? tapb[kx][ks] : (C::ZERO_OFF - (cc & 1) * C::HBUF_HALFS - imm);
+          bf[t % BD] = *reinterpret_cast<const half8 *>(&halo[base + imm]);
+        };
+        load_a(0, 0);
+        load_b(IC<0>{});
+        load_b(IC<1>{});
+        load_b(IC<2>{});
+        load_b(IC<3>{});
+        __builtin_amdgcn_sched_barrier(0);
+        auto visit = [&](auto tc) __attribute__((always_inline)) {
+          constexpr int t = decltype(tc)::value, st = t / NT, j = t % NT, cur = st & 1;
+          if constexpr (j == 0 && st + 1 < 6) {
+            load_a(st + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][0], bf[t % BD], acc[0][j], 0, 0, 0);
+          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][1], bf[t % BD], acc[1][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (t + BD < NV) load_b(IC<t + BD>{});
+          static_assert(WQ + HQ <= NV, "DMA issue slots");
+          if constexpr (t < WQ) {
+            if (more_w) wstage(c0w, ncc, nky, buf ^ 1, IC<t>{}, IC<t + 1>{});
+          } else if constexpr (t - WQ < HQ) {
+            if (more_h) halo_dma(hgr0, hcc, (cc + 1) & 1, IC<t - WQ>{});
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+#define V4(a) visit(IC<(a)>{}); visit(IC<(a) + 1>{}); visit(IC<(a) + 2>{}); visit(IC<(a) + 3>{});
+        V4(0) V4(4) V4(8) V4(12) V4(16) V4(20)
+#undef V4
+      }
+    }
+
+    // ---------------- epilogue: per-wave staging in the band buffer the last chunk has just released ----------------
+    // (an even chunk count: the last chunk read buffer 1, the next tile's chunk 0 sits in buffer 0 and its chunk 1 is requested
+    // only behind the next group's barrier.)  One barrier, so that no wave still reads buffer 1; then every wave turns its 128
+    // pixels x 64 channels around on its own: residual rows in (16-byte loads, 128 bytes per pixel), fp32 add / ReLU exactly as
+    // the staged epilogue of halo_tile_dma does, rows out (16-byte stores).
+    const int rpx = lane >> 3, c16 = lane & 7;              // row form: instruction u covers pixels 8u .. 8u+7, 8 lanes x 16 B each
+    u32x4 rv[RES ? NT : 1][4];
+    if constexpr (RES) {
+      // all 16 residual row segments of the wave are requested at once, ahead of the barrier (the fragment registers of the
+      // main loop are dead here): one memory round trip per tile instead of one per 32-pixel tile
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int mr = min(m0 + wn * PXW + j * 32 + u * 8 + rpx, p.M - 1);
+          rv[j][u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)mr * p.Cout + c0 + wm * 64 + c16 * 8);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      constexpr int PLD = 72;                               // halfs per staged pixel (64 channels + 8 pad = 144 B)
+      static_assert(8 * 32 * PLD <= C::HBUF_HALFS, "the per-wave staging slices fit one band buffer");
+      f16 *stage = lds + C::HBUF_HALFS + wave * (32 * PLD);
+      const float lo = p.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int mt = m0 + wn * PXW + j * 32;              // first pixel of this 32-pixel tile
+        if constexpr (RES) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4 *>(&stage[(u * 8 + rpx) * PLD + c16 * 8]) = rv[j][u];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
+            f16 *sp = &stage[lr * PLD + i * 32 + rg * 8 + lh * 4];
+            if constexpr (RES) {
+              const half4 rq = *reinterpret_cast<const half4 *>(sp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)rq[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+            half4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
+            *reinterpret_cast<half4 *>(sp) = hv;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u32x4 ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ov[u] = *reinterpret_cast<const u32x4 *>(&stage[(u * 8 + rpx) * PLD + c16 * 8]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int mr = mt + u * 8 + rpx, mc = min(mr, p.M - 1);
+          const bool hi = mc >= p.split_m;
+          f16 *o = (f16 *)p.out + (hi ? (long long)(mc - p.split_m) : (long long)mc) * p.out_ld + (hi ? p.coff_hi : 0) + c0 + wm * 64 + c16 * 8;
+          if (mr < p.M) *reinterpret_cast<u32x4 *>(o) = ov[u];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are in registers before the next tile's values overwrite them
+      }
+    }
+    prev_full = m0 + TM <= p.M;
+    m0 = m0n;
+    c0 = c0n;
+  }
+}
+
+template <int W, bool RES, bool POST>
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_persist_kernel(ConvArgs p, int rounds) {
+  extern __shared__ __attribute__((aligned(16))) f16 lds[];
+  halo_persist<W, RES, POST>(p, gridDim.x, rounds, lds);
+}
+
+#endif   // HALO_STAMP (persistent form)
+
+template <int W, bool RES, bool POST>
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, int n_main, int tile0) {
   extern __shared__ __attribute__((aligned(16))) f16 lds[];
   constexpr int TMM = 512;
   const int n_ct = p.Cout / HL_BM;
+  // tile0: logical tiles before it were done by the persistent launch (0 when this launch is the whole layer)
   if ((int)blockIdx.x < n_main) {
-    const int L = xcd_remap(blockIdx.x, n_main);
+    const int L = tile0 + xcd_remap(blockIdx.x, n_main);
     halo_tile_dma<W, 4, RES, POST>(p, (L / n_ct) * TMM, (L % n_ct) * HL_BM, lds);
   } else {
     const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
-    const int L = n_main + (t >> 2);
+    const int L = tile0 + n_main + (t >> 2);
     const int m0 = (L / n_ct) * TMM + (t & 3) * (TMM / 4);
     if (m0 >= p.M) return;
     halo_tile_dma<W, 1, RES, POST>(p, m0, (L % n_ct) * HL_BM, lds);
@@ -899,7 +1196,27 @@ static int launch_halo_dma(const ConvArgs &a, hipStream_t s) {
   const int n_tiles = ((a.M + 511) / 512) * (a.Cout / HL_BM);
   int n_main, n_tail4;
   halo_split(n_tiles, slots, &n_main, &n_tail4);
-  hipLaunchKernelGGL((conv3x3_halo_dma_kernel<W, RES, POST>), dim3(n_main + n_tail4), dim3(512), C::LDS_BYTES, s, a, n_main);
+  int tile0 = 0;
+#ifdef HALO_STAMP
+  // diagnostic builds, FP_HALO_PERSIST=1: two or more whole rounds go to the persistent form, the remainder - whole tiles or
+  // quarter tiles, as halo_split decided - follows as a launch of the per-tile form
+  static const bool persist_on = getenv("FP_HALO_PERSIST") && atoi(getenv("FP_HALO_PERSIST")) == 1;
+  static bool attr_p = false;
+  const int rounds = n_main / slots;
+  if constexpr (!POST) {            // (the positional-embedding layer stays on the per-tile form: its fp32 rows do not fit the staging slices)
+    if (persist_on && rounds >= 2 && (a.Cin / HL_CK) % 2 == 0) {          // (the band buffers alternate per chunk across tiles: an even chunk count)
+      if (!attr_p) {
+        FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_persist_kernel<W, RES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        attr_p = true;
+      }
+      hipLaunchKernelGGL((conv3x3_halo_persist_kernel<W, RES, false>), dim3(slots), dim3(512), C::LDS_BYTES, s, a, rounds);
+      tile0 = rounds * slots;
+      n_main -= tile0;
+    }
+  }
+#endif
+  if (n_main + n_tail4 > 0)
+    hipLaunchKernelGGL((conv3x3_halo_dma_kernel<W, RES, POST>), dim3(n_main + n_tail4), dim3(512), C::LDS_BYTES, s, a, n_main, tile0);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -341,6 +341,7 @@ def _pack_conv_weight(w, cin_pad):
   (2, 80, 80, 64, 128, 3, 2, False, True),
   (3, 20, 20, 512, 512, 3, 1, True, True),
   (2, 40, 40, 256, 512, 3, 2, False, True),
+  (328, 40, 40, 128, 128, 3, 1, True, True),        # 1025 tiles: four full rounds + one tile (quarter tiles for the remainder)
   (9, 40, 40, 256, 512, 3, 2, False, True),         # band-in-LDS stride-2 kernel (conv_s2.hip): 8-row tiles straddle images, last tile partial
   (9, 40, 40, 64, 128, 3, 2, False, False),         # the same with 128-cout blocks, no ReLU
   (2, 160, 160, 6, 64, 7, 2, False, True),
