@@ -466,7 +466,6 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
     TAKE(bbox, float, (size_t)N * 4);
     TAKE(trans, float, (size_t)N * 3);
     TAKE(rot, float, (size_t)N * 6);
-    TAKE(pose_tmp, float, (size_t)N * 16);
     TAKE(net_in, f16, (size_t)2 * N * img);
     float *tr = d_trans ? d_trans : trans, *ro = d_rot ? d_rot : rot;
     const int n_runs = count_runs(objs, n_obj);
@@ -509,11 +508,10 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
         if (cnt > 0)
           FP_TRY(launch_pose_update(d_poses + (size_t)off * 16, tr + (size_t)off * 3, ro + (size_t)off * rot_dim, cnt, rot_dim,
                                     cfg->trans_rep_tanh, cfg->trans_normalizer[0], cfg->trans_normalizer[1], cfg->trans_normalizer[2],
-                                    cfg->rot_normalizer, trans_scale, pose_tmp + (size_t)off * 16, s, tf + (size_t)off * 9, objs[o].K, 160.f));
+                                    cfg->rot_normalizer, trans_scale, d_poses + (size_t)off * 16, s, tf + (size_t)off * 9, objs[o].K, 160.f));      // in place
         off += cnt;
         o = e;
       }
-      FP_CHECK_HIP(hipMemcpyAsync(d_poses, pose_tmp, (size_t)N * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return FP_OK;
   };

@@ -722,7 +722,9 @@ __global__ void pose_update_kernel(const float *__restrict__ poseA, const float 
                                    float trans_scale, DeepimArgs dp, float *__restrict__ outp) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= N) return;
-  const float *A = poseA + (size_t)b * 16;
+  float A[12];                 // the pose is read completely before anything is written: outp may be poseA (in-place update)
+#pragma unroll
+  for (int i = 0; i < 12; ++i) A[i] = poseA[(size_t)b * 16 + i];
   float td[3] = {trans[b * 3], trans[b * 3 + 1], trans[b * 3 + 2]};
   if (trans_tanh == 1) {
     td[0] = tanhf(td[0]) * tn0;
