@@ -2,8 +2,8 @@
 argmax) on 252 hypotheses x 160x160 crops of ONE object - BASELINE.json's metric on configs[1] (one GPU) /
 configs[2] (the same object, its hypotheses sharded over N GPUs).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a rendezvous in the environment: starts its own N ranks)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...       (the driver's form; WORLD_SIZE must equal N)
 
 One "step" = one register-core pass: est_refine_iter=5 x (crop window, render,
 observed crop, RefineNet, pose update) + 1 x (crop window, render, observed crop, ScoreNet features)
@@ -227,33 +227,96 @@ def cpu_baseline():
                      f'pass: oracle/ (torch-CPU fp32 nets + C/OpenMP rasteriser), {dt:.1f} s wall incl. depth filtering')
 
 
-def main():
+def launch_ranks(args, argv):
+  """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: this process becomes the launcher.  It starts
+  N fresh ranks as a CHILD (`python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>`) before anything here
+  has touched the GPU, relays the child's output (rank 0's JSON line is the last line of stdout) and returns the child's exit
+  status.  Never exec: replacing a process that may have initialised HIP takes the node down on this pool."""
+  import socket
+  import subprocess
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  port = s.getsockname()[1]
+  s.close()
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
+  env.setdefault('OMP_NUM_THREADS', '4')
+  print(f'bench.py: starting {args.gpus} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
+  return subprocess.call(cmd, env=env)
+
+
+def launch_check(world, rank, device, backend):
+  """--launch-check: rendezvous only.  Every rank all-gathers its rank id through the process group the bench would use and rank 0
+  prints one JSON line - what a CPU test (gloo) and a first minute on a multi-GPU node (nccl = RCCL) use to see that `--gpus N`
+  really runs N ranks."""
+  mine = torch.tensor([rank], device=device, dtype=torch.int64)
+  got = [torch.zeros_like(mine) for _ in range(world)]
+  if world > 1:
+    dist.all_gather(got, mine)
+  else:
+    got = [mine]
+  ranks = [int(g.item()) for g in got]
+  assert ranks == list(range(world)), ranks
+  if rank == 0:
+    print(json.dumps({'launch_check': True, 'n_gpus': world, 'rccl_ranks': dist.get_world_size() if world > 1 else 1,
+                      'backend': backend, 'ranks': ranks}), flush=True)
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main(argv=None):
+  argv = sys.argv[1:] if argv is None else argv
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=10)
   ap.add_argument('--warmup', type=int, default=2)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true', help='headline only: skip the weak-scaling / configs[3] / tracking figures')
-  args = ap.parse_args()
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-  if not torch.cuda.is_available():
-    raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+  ap.add_argument('--launch-check', action='store_true', help='rendezvous only: start the ranks, all-gather the rank ids, print them')
+  args = ap.parse_args(argv)
+  if args.gpus < 1:
+    raise SystemExit('--gpus must be >= 1')
   # FP_BENCH_REHEARSAL=1: every rank on cuda:0 with the gloo backend - rehearses the multi-process flow (rendezvous, barriers,
   # the all-gather, finalisation) on a one-GPU box; the numbers it prints mean nothing
   rehearsal = os.environ.get('FP_BENCH_REHEARSAL') == '1'
+  if 'WORLD_SIZE' not in os.environ:
+    if args.gpus > 1:             # nobody started the ranks: do it here, before any GPU call (device_count() makes none)
+      have = torch.cuda.device_count()
+      if not (rehearsal or args.launch_check) and have < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: this node exposes {have} GPU(s); refusing to report a {args.gpus}-GPU figure from fewer')
+      raise SystemExit(launch_ranks(args, argv))
+    world, rank, local_rank = 1, 0, 0
+  else:
+    world = int(os.environ['WORLD_SIZE'])
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+      raise SystemExit(f'bench.py --gpus {args.gpus} but the launcher set WORLD_SIZE={world}: the n_gpus of the JSON line would be wrong')
+  os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+  if args.launch_check and not torch.cuda.is_available():       # the CPU form of the rendezvous check (tests/test_dist_gloo.py)
+    if world > 1:
+      dist.init_process_group('gloo')
+    return launch_check(world, rank, torch.device('cpu'), 'gloo')
+  if not torch.cuda.is_available():
+    raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
   if rehearsal:
     local_rank = 0
+  elif local_rank >= torch.cuda.device_count():
+    raise SystemExit(f'rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible')
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
+  backend = 'single-process'
   if world > 1:
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    backend = 'gloo' if rehearsal else 'nccl'
     if rehearsal:
       dist.init_process_group('gloo')
     else:
       dist.init_process_group('nccl', device_id=device)
+  if args.launch_check:
+    return launch_check(world, rank, device, backend)
 
   n_obj = max(world, 1 if args.no_extras else 4)
   est, objects = build_job(device, n_objects=n_obj, rank=rank)
@@ -333,6 +396,7 @@ def main():
     out = {
       'metric': 'pose-hypotheses/sec (render+refine+score), 252 hyp x 160x160',
       'value': total_hyp / dt, 'unit': 'pose-hypotheses/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+      'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'collective_backend': backend,
       'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
       'dtype': 'f16', 'data': 'synthetic',
       'config': {'workload': ('configs[1]' if world == 1 else 'configs[2]') + ': ONE object (mesh 8066 v / 16128 f), 252 hypotheses, '

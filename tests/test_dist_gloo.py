@@ -167,3 +167,32 @@ def test_bench_step_layouts_world2():
     assert p.exitcode == 0
   assert all(a and b for _, a, b, _ in res)
   assert len({am for _, _, _, am in res}) == 1
+
+
+def _run_bench(args, env_extra=None, timeout=180):
+  import subprocess
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'FP_BENCH_REHEARSAL')}
+  env.update(env_extra or {})
+  return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks():
+  """`python bench.py --gpus 2` without a rendezvous in the environment must start 2 ranks itself (a child torch.distributed.run,
+  never an exec) and relay rank 0's JSON line; --launch-check stops after the rendezvous + one all-gather of the rank ids, which
+  on this GPU-less container runs over gloo."""
+  import json
+  r = _run_bench(['--gpus', '2', '--launch-check'])
+  assert r.returncode == 0, r.stderr[-2000:]
+  line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+  assert line['n_gpus'] == 2 and line['rccl_ranks'] == 2 and line['ranks'] == [0, 1]
+  assert 'torch.distributed.run' in r.stderr          # the launcher says what it started
+
+
+def test_bench_refuses_a_mislabelled_run():
+  """WORLD_SIZE != --gpus, or --gpus N on a node with fewer GPUs, must fail loudly instead of printing n_gpus: 1."""
+  r = _run_bench(['--gpus', '2', '--launch-check'], {'WORLD_SIZE': '3', 'RANK': '0'})
+  assert r.returncode != 0 and 'WORLD_SIZE=3' in r.stderr
+  if torch.cuda.device_count() < 8:
+    r = _run_bench(['--gpus', '8'])
+    assert r.returncode != 0 and 'refusing' in r.stderr
+    assert not any(l.startswith('{') for l in r.stdout.splitlines())
