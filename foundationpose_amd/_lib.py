@@ -259,31 +259,40 @@ def object_batches(ctx, objects, geom_key):
 
 
 class DeviceNet:
-  """fp_net built from a reference-layout state_dict (torch tensors)."""
+  """fp_net built from a reference-layout state_dict (torch tensors).  The float32 host copies of the parameters are kept, so
+  the network can be rebuilt on another device (`to`, the counterpart of nn.Module.to in src/estimater.py:97-100)."""
 
   def __init__(self, ctx, kind, state_dict, use_bn=True):
-    keep = []
-    arr = (FpTensor * len(state_dict))()
-    n = 0
-    for k, v in state_dict.items():
-      if not torch.is_tensor(v) or not v.dtype.is_floating_point:
-        continue
-      a = np.ascontiguousarray(v.detach().cpu().float().numpy())
-      keep.append(a)
-      kb = k.encode()
-      keep.append(kb)
+    self._host = [(k.encode(), np.ascontiguousarray(v.detach().cpu().float().numpy())) for k, v in state_dict.items()
+                  if torch.is_tensor(v) and v.dtype.is_floating_point]
+    self.kind = kind
+    self.use_bn = bool(use_bn)
+    self.handle = None
+    self._create(ctx)
+
+  def _create(self, ctx):
+    arr = (FpTensor * len(self._host))()
+    for n, (kb, a) in enumerate(self._host):
       arr[n].name = kb
       arr[n].data = a.ctypes.data
       arr[n].ndim = a.ndim
       for i in range(min(a.ndim, 4)):
         arr[n].shape[i] = a.shape[i]
-      n += 1
     h = c_void_p()
-    check(lib().fp_net_create(ctx.handle, kind, arr, n, 1 if use_bn else 0, byref(h)))
+    check(lib().fp_net_create(ctx.handle, self.kind, arr, len(self._host), 1 if self.use_bn else 0, byref(h)))
     self.handle = h
     self.ctx = ctx
-    self.kind = kind
-    self.rot_dim = lib().fp_net_rot_dim(h) if kind == FP_NET_REFINE else 0
+    self.rot_dim = lib().fp_net_rot_dim(h) if self.kind == FP_NET_REFINE else 0
+
+  def to(self, device):
+    """Move the packed weights to `device` (a torch device / string): a no-op on the same device, otherwise the fp_net is
+    rebuilt there from the host copies and the old one freed.  Returns self, like nn.Module.to."""
+    ctx = Context.get(device)
+    if ctx.device_index != self.ctx.device_index:
+      old = self.handle
+      self._create(ctx)
+      lib().fp_net_destroy(old)
+    return self
 
   def __del__(self):
     try:

@@ -48,3 +48,30 @@ def load_run_dir(run_name, weights_root=None):
     ckpt = ckpt['model']
   cfg['ckpt_dir'] = ckpt_dir
   return ckpt, cfg
+
+
+def check_network_cfg(cfg, state_dict, stem_key, ref_file):
+  """The configurations the HIP networks are built for, checked BEFORE anything touches the device, each refusal naming the
+  reference lines whose behaviour would be needed (learning/training/<ref_file>).  Everything else the reference's config
+  offers (use_BN, normalize_xyz, crop_ratio, trans_rep, rot_rep, zfar) is implemented."""
+  size = tuple(int(x) for x in cfg['input_resize'])
+  if size != (160, 160):
+    raise NotImplementedError(
+      f"input_resize={list(size)}: the HIP trunk is laid out for 160x160 crops (80/40/20-pixel feature maps, 400 tokens = "
+      f"pos_embed max_len, network_modules.py:115-137).  The reference renders at input_resize ({ref_file}:38-49, output_size=cfg['input_resize']) "
+      f"and only warps side A again when the sizes differ ({ref_file}:64-71); no released model uses another size")
+  if cfg.get('use_normal', False):
+    raise NotImplementedError(
+      f"use_normal=True (9-channel inputs: {ref_file} normalAs/normalBs, src/Utils.py:191-199) is not implemented: no released model has the "
+      f"9-channel stem, and the reference's own estimator cannot reach the branch (src/estimater.py:215,263 call predict() without normal_map, "
+      f"which {ref_file} would hand to torch.as_tensor(None))")
+  stem = state_dict.get(stem_key) if hasattr(state_dict, 'get') else None
+  if stem is not None:
+    c_sd = int(stem.shape[1])
+    if int(cfg['c_in']) != c_sd:
+      raise ValueError(f"config c_in={cfg['c_in']} but '{stem_key}' has {c_sd} input channels: the reference builds the model with "
+                       f"c_in=cfg['c_in'] and load_state_dict would raise on the size mismatch ({ref_file}: model = ...(c_in=self.cfg['c_in']); "
+                       f"note the back-compat default c_in=4 when the key is absent)")
+    if c_sd != 6:
+      raise ValueError(f"c_in={c_sd}: predict() feeds 6 channels, cat([rgb, xyz_map], 1) ({ref_file}: A = torch.cat([rgbAs, xyz_mapAs], dim=1)), "
+                       f"so a stem with {c_sd} input channels raises in the reference's first convolution; only c_in=6 checkpoints can run")

@@ -233,6 +233,20 @@ extern "C" int fp_crop_window_tf(fp_ctx *ctx, const float *d_poses, int N, const
   return launch_crop_window_tf(d_poses, N, K, crop_ratio, mesh_diameter, out_w, out_h, d_tf, d_bbox2d, (hipStream_t)stream);
 }
 
+// A render called on its own (the nvdiffrast_render API, fp_render_net): its scratch (transformed vertices + strip face lists) comes
+// from the context's arena and is released when the launches are queued - the next taker runs behind them on the same stream.
+static int render_with_arena_scratch(fp_ctx *ctx, RenderArgs &a, hipStream_t s) {
+  if (a.N <= 0) return launch_render(ctx, a, s);
+  const RenderPlan pl = render_plan(a.N, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
+  FP_TRY(fp_arena_ensure(ctx, pl.total + 4096));
+  const size_t mark = ctx->arena.off;
+  a.scratch = ctx->arena.take(pl.total);
+  a.scratch_bytes = pl.total;
+  const int rc = a.scratch ? launch_render(ctx, a, s) : FP_ENOMEM;
+  ctx->arena.off = mark;
+  return rc;
+}
+
 static int fill_render(RenderArgs &a, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
                        const float *d_bbox2d, int out_h, int out_w) {
   FP_REQUIRE(mesh && K && (d_poses || N == 0), "render: null argument");
@@ -263,7 +277,7 @@ extern "C" int fp_render(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses,
   a.depth = d_depth;
   a.normal = d_normal;
   a.xyz = d_xyz;
-  return launch_render(ctx, a, (hipStream_t)stream);
+  return render_with_arena_scratch(ctx, a, (hipStream_t)stream);
 }
 
 extern "C" int fp_render_ex(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
@@ -288,13 +302,13 @@ extern "C" int fp_render_ex(fp_ctx *ctx, const fp_mesh *mesh, const float *d_pos
   a.depth = d_depth;
   a.normal = d_normal;
   a.xyz = d_xyz;
-  return launch_render(ctx, a, (hipStream_t)stream);
+  return render_with_arena_scratch(ctx, a, (hipStream_t)stream);
 }
 
-// vscratch: optional N * V * 16 bytes for the vertex pre-pass (nullptr: every triangle transforms its own vertices)
+// scratch: render_plan(N, ...).total bytes for the vertex pre-pass and the strip face lists (nullptr: taken from the arena here)
 static int render_net_impl(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
                            const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
-                           void *d_net_out, void *vscratch, void *stream) {
+                           void *d_net_out, void *scratch, size_t scratch_bytes, void *stream) {
   FP_REQUIRE(ctx && d_net_out, "fp_render_net: null argument");
   RenderArgs a;
   FP_TRY(fill_render(a, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w));
@@ -305,7 +319,9 @@ static int render_net_impl(fp_ctx *ctx, const fp_mesh *mesh, const float *d_pose
   a.mesh_diameter = (float)mesh_diameter;
   a.invalid_thres = invalid_thres;
   a.normalize_xyz = normalize_xyz;
-  a.vbuf = vscratch;
+  if (!scratch) return render_with_arena_scratch(ctx, a, (hipStream_t)stream);
+  a.scratch = scratch;
+  a.scratch_bytes = scratch_bytes;
   return launch_render(ctx, a, (hipStream_t)stream);
 }
 
@@ -313,7 +329,7 @@ extern "C" int fp_render_net(fp_ctx *ctx, const fp_mesh *mesh, const float *d_po
                              const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
                              void *d_net_out, void *stream) {
   return render_net_impl(ctx, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w, mesh_diameter, normalize_xyz, invalid_thres, d_net_out,
-                         nullptr, stream);
+                         nullptr, 0, stream);
 }
 
 extern "C" int fp_crop_observed(fp_ctx *ctx, const float *d_rgb, const float *d_geom, int H, int W, const double *K, const float *d_tf,
@@ -424,18 +440,23 @@ static bool same_render_key(const fp_object_batch &a, const fp_object_batch &b) 
   return a.mesh == b.mesh && a.H == b.H && a.W == b.W && a.mesh_diameter == b.mesh_diameter && memcmp(a.K, b.K, 9 * sizeof(double)) == 0;
 }
 
-// Scratch for the renderer's vertex pre-pass: 16 bytes per (hypothesis, vertex) over all objects, from the arena's slack if it
-// is there (nullptr otherwise: the renderer then transforms vertices per triangle - slower, same result).
-static char *take_vertex_scratch(fp_ctx *ctx, const fp_object_batch *objs, int n_obj) {
+// Scratch of the renders of a pass: one render_plan(...).total per run of like objects (the renders of the runs may overlap on side
+// streams, so each has its own block).
+static size_t render_scratch_total(fp_ctx *ctx, const fp_object_batch *objs, int n_obj) {
   size_t bytes = 0;
-  int n = 0;
-  for (int o = 0; o < n_obj; ++o) {
-    bytes += (size_t)objs[o].n * (size_t)(objs[o].mesh ? objs[o].mesh->d.V : 0) * 16;
-    n += objs[o].n;
+  for (int o = 0; o < n_obj;) {
+    int e = o + 1, cnt = objs[o].n;
+    while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
+    if (cnt > 0) bytes += (render_plan(cnt, objs[o].mesh->d.V, objs[o].mesh->d.F, 160, 160, ctx->num_cu).total + 255) & ~(size_t)255;
+    o = e;
   }
-  // the network pass that follows allocates fp_arena_inner_bytes(n) from the same arena: leave that room
-  if (bytes == 0 || ctx->arena.cap - ctx->arena.off < bytes + fp_arena_inner_bytes(n) + ((size_t)1 << 20)) return nullptr;
-  return (char *)ctx->arena.take(bytes);
+  return bytes;
+}
+
+// arena bytes of a fused pass over N hypotheses: crop transforms, the two net-input sides (0.82 MB per hypothesis), the render
+// scratch, the network forward
+static size_t pass_arena_bytes(int N, size_t render_scratch) {
+  return (size_t)N * ((size_t)1 << 20) + ((size_t)1 << 20) + render_scratch + fp_arena_inner_bytes(N);
 }
 
 static int count_runs(const fp_object_batch *objs, int n_obj) {
@@ -458,7 +479,8 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
   if (N == 0 || iteration == 0) return FP_OK;
   hipStream_t s = (hipStream_t)stream;
   const int rot_dim = fp_net_rot_dim(net);
-  FP_TRY(fp_arena_ensure(ctx, fp_arena_bytes_for(N)));
+  const size_t rs_total = render_scratch_total(ctx, objs, n_obj);
+  FP_TRY(fp_arena_ensure(ctx, pass_arena_bytes(N, rs_total)));
   const size_t mark = ctx->arena.off;
   const size_t img = (size_t)160 * 160 * 8;
   auto body = [&]() -> int {
@@ -469,7 +491,7 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
     TAKE(net_in, f16, (size_t)2 * N * img);
     float *tr = d_trans ? d_trans : trans, *ro = d_rot ? d_rot : rot;
     const int n_runs = count_runs(objs, n_obj);
-    char *vscratch = take_vertex_scratch(ctx, objs, n_obj);     // reused by every iteration
+    TAKE(rscratch, char, rs_total);                              // reused by every iteration
     for (int it = 0; it < iteration; ++it) {
       size_t voff = 0;
       int off = 0, k = 0;
@@ -482,9 +504,10 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
           hipStream_t so = fo.stream_for(k++);
           float *p = d_poses + (size_t)off * 16;
           FP_TRY(launch_crop_window_tf(p, cnt, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
+          const size_t rsb = (render_plan(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu).total + 255) & ~(size_t)255;
           FP_TRY(render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
-                                 cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, vscratch ? vscratch + voff : nullptr, so));
-          voff += (size_t)cnt * ob.mesh->d.V * 16;
+                                 cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, rscratch + voff, rsb, so));
+          voff += rsb;
           for (int q = o; q < e; ++q) {
             const fp_object_batch &oq = objs[q];
             if (oq.n == 0) continue;
@@ -535,7 +558,8 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
   FP_TRY(check_objs(objs, n_obj, &N));
   if (N == 0) return FP_OK;
   hipStream_t s = (hipStream_t)stream;
-  FP_TRY(fp_arena_ensure(ctx, fp_arena_bytes_for(N)));
+  const size_t rs_total = render_scratch_total(ctx, objs, n_obj);
+  FP_TRY(fp_arena_ensure(ctx, pass_arena_bytes(N, rs_total)));
   const size_t mark = ctx->arena.off;
   const size_t img = (size_t)160 * 160 * 8;
   auto body = [&]() -> int {
@@ -543,7 +567,7 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
     TAKE(bbox, float, (size_t)N * 4);
     TAKE(net_in, f16, (size_t)2 * N * img);
     int off = 0, k = 0;
-    char *vscratch = take_vertex_scratch(ctx, objs, n_obj);
+    TAKE(rscratch, char, rs_total);
     size_t voff = 0;
     StreamFanout fo(ctx, s, count_runs(objs, n_obj));
     for (int o = 0; o < n_obj;) {
@@ -554,9 +578,10 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
         hipStream_t so = fo.stream_for(k++);
         const float *p = d_poses + (size_t)off * 16;
         FP_TRY(launch_crop_window_tf(p, cnt, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
+        const size_t rsb = (render_plan(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu).total + 255) & ~(size_t)255;
         FP_TRY(render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
-                               net_in + (size_t)off * img, vscratch ? vscratch + voff : nullptr, so));
-        voff += (size_t)cnt * ob.mesh->d.V * 16;
+                               net_in + (size_t)off * img, rscratch + voff, rsb, so));
+        voff += rsb;
         for (int q = o; q < e; ++q) {
           const fp_object_batch &oq = objs[q];
           if (oq.n == 0) continue;

@@ -356,91 +356,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// LayerNorm over 512 features, one wave per row (8 values per lane), fp32 in -> fp16 out.
-__device__ __forceinline__ void load8(const float *p, float *v) {
-  const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-__device__ __forceinline__ void load8(const f16 *p, float *v) {
-  const half8 h = *reinterpret_cast<const half8 *>(p);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
-}
-
-template <typename TI>
-__global__ __launch_bounds__(256) void layernorm_kernel(const TI *__restrict__ x, const float *__restrict__ gam,
-                                                        const float *__restrict__ bet, int M, f16 *__restrict__ out) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  float v[8];
-  load8(x + (size_t)row * 512 + lane * 8, v);
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) s += v[i];
-  const float mean = wave_sum(s) * (1.f / 512.f);
-  float sq = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v[i] -= mean;
-    sq += v[i] * v[i];
-  }
-  const float rstd = rsqrtf(wave_sum(sq) * (1.f / 512.f) + 1e-5f);
-  half8 hv;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) hv[i] = (f16)(v[i] * rstd * gam[lane * 8 + i] + bet[lane * 8 + i]);
-  *reinterpret_cast<half8 *>(out + (size_t)row * 512 + lane * 8) = hv;
-}
-
-int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s) {
-  if (M == 0) return FP_OK;
-  hipLaunchKernelGGL(layernorm_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, M, out);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-int launch_layernorm_h(const f16 *x, const float *g, const float *b, int M, f16 *out, hipStream_t s) {
-  if (M == 0) return FP_OK;
-  hipLaunchKernelGGL(layernorm_kernel<f16>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, M, out);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-// Final LayerNorm + mean over the T tokens of one hypothesis + Linear(512 -> out_dim<=6):
-// mean_t(Linear(LN(x_t))) == Linear(mean_t LN(x_t))  (refine_network.py:90-91).
-// Two launches so that 252 hypotheses fill the chip: (1) LNP_SPLIT workgroups per hypothesis sum the
-// normalised rows of their token range -> partial[b][part][512]; (2) one small workgroup per hypothesis
-// adds the partials in a fixed order (deterministic), applies gamma/beta and the output Linear.
-#define LNP_SPLIT 8
-template <typename TI>
-__global__ __launch_bounds__(256) void ln_partial_kernel(const TI *__restrict__ x, int T, float *__restrict__ partial) {
-  __shared__ float part[4][512];
-  const int b = blockIdx.x / LNP_SPLIT, q = blockIdx.x % LNP_SPLIT, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per = (T + LNP_SPLIT - 1) / LNP_SPLIT, t0 = q * per, t1 = min(T, t0 + per);
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int t = t0 + wave; t < t1; t += 4) {
-    float v[8];
-    load8(x + ((size_t)b * T + t) * 512 + lane * 8, v);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += v[i];
-    const float mean = wave_sum(s) * (1.f / 512.f);
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v[i] -= mean;
-      sq += v[i] * v[i];
-    }
-    const float rstd = rsqrtf(wave_sum(sq) * (1.f / 512.f) + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += v[i] * rstd;
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) part[wave][lane * 8 + i] = acc[i];
-  __syncthreads();
-  for (int f = threadIdx.x; f < 512; f += 256)
-    partial[((size_t)b * LNP_SPLIT + q) * 512 + f] = (part[0][f] + part[1][f]) + (part[2][f] + part[3][f]);
-}
-
+// Token mean + output Linear behind the final LayerNorm of a RefineNet head:
+// mean_t(Linear(LN(x_t))) == Linear(mean_t LN(x_t))  (refine_network.py:90-91).  The LayerNorm itself runs in the epilogue of
+// linear2 (tok_gemm.hip, EPI_LNSUM), which leaves the sums of the normalised rows over groups of 16 tokens; one small workgroup
+// per hypothesis adds these partial rows in a fixed order (deterministic), applies gamma / beta and the output Linear.
 __global__ __launch_bounds__(512) void mean_head_kernel(const float *__restrict__ partial, int nparts, const float *__restrict__ gam,
                                                         const float *__restrict__ bet, int T, const float *__restrict__ hw,
                                                         const float *__restrict__ hb, int out_dim, float *__restrict__ out) {
@@ -470,28 +389,10 @@ __global__ __launch_bounds__(512) void mean_head_kernel(const float *__restrict_
   }
 }
 
-int launch_ln_mean_head(const float *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb, int out_dim,
-                        float *out, float *scratch, hipStream_t s) {
-  if (Bn == 0) return FP_OK;
-  hipLaunchKernelGGL(ln_partial_kernel<float>, dim3(Bn * LNP_SPLIT), dim3(256), 0, s, x, T, scratch);
-  hipLaunchKernelGGL(mean_head_kernel, dim3(Bn), dim3(512), 0, s, scratch, LNP_SPLIT, g, b, T, hw, hb, out_dim, out);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
 int launch_mean_head(const float *partial, int nparts, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
                      int out_dim, float *out, hipStream_t s) {
   if (Bn == 0) return FP_OK;
   hipLaunchKernelGGL(mean_head_kernel, dim3(Bn), dim3(512), 0, s, partial, nparts, g, b, T, hw, hb, out_dim, out);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-int launch_ln_mean_head_h(const f16 *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb, int out_dim,
-                          float *out, float *scratch, hipStream_t s) {
-  if (Bn == 0) return FP_OK;
-  hipLaunchKernelGGL(ln_partial_kernel<f16>, dim3(Bn * LNP_SPLIT), dim3(256), 0, s, x, T, scratch);
-  hipLaunchKernelGGL(mean_head_kernel, dim3(Bn), dim3(512), 0, s, scratch, LNP_SPLIT, g, b, T, hw, hb, out_dim, out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
@@ -611,6 +512,7 @@ __global__ __launch_bounds__(256) void cross_attention_kernel(const float *__res
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int u = 0; u < 4; ++u) kr[u] = reinterpret_cast<const float4 *>(base + (size_t)min(j0 + 64 * u, L - 1) * 1536 + 512 + hd * 128);
+#pragma unroll 4                                   // (fully unrolled, hipcc held 128 float4 loads live: 512 VGPRs and 87 spilled)
     for (int d4 = 0; d4 < 32; ++d4) {
       float4 kv[4];
 #pragma unroll

@@ -245,12 +245,6 @@ int launch_tok_gemm(fp_ctx *ctx, const TokGemmArgs &a, int epi, hipStream_t s);
 // Sum of `nparts` consecutive partial rows per hypothesis (fixed order) / T, gamma, beta, Linear(512 -> out_dim)
 int launch_mean_head(const float *partial, int nparts, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
                      int out_dim, float *out, hipStream_t s);
-int launch_layernorm(const float *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
-int launch_layernorm_h(const f16 *x, const float *g, const float *b, int M, f16 *out, hipStream_t s);
-int launch_ln_mean_head_h(const f16 *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
-                          int out_dim, float *out, float *scratch /* Bn*8*512 */, hipStream_t s);
-int launch_ln_mean_head(const float *x, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
-                        int out_dim, float *out, float *scratch /* Bn*8*512 */, hipStream_t s);
 int launch_token_mean(const f16 *x, int Bn, int T, float *out, hipStream_t s);
 int launch_small_linear(const float *x, const float *w, const float *wt, const float *b, int M, int K, int N, float *out, hipStream_t s);
 int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s);
@@ -271,7 +265,8 @@ struct RenderArgs {
   f16 *net_out;                         // mode 1
   float mesh_diameter, invalid_thres;
   int normalize_xyz;
-  void *vbuf = nullptr;                 // optional scratch, N * V * 16 B: transformed vertices (render pre-pass)
+  void *scratch = nullptr;              // render_plan(...).total bytes: transformed vertices, per-strip face lists (required)
+  size_t scratch_bytes = 0;
   // non-default lighting / projection of nvdiffrast_render (src/Utils.py:159-162,200-211)
   int light_mode = 0;                   // 0: light_dir = (0,0,1), the default; 1: direction light_vec = -light_dir; 2: point light at light_vec (light_dir=None)
   float light_vec[3] = {0.f, 0.f, -1.f};
@@ -280,6 +275,11 @@ struct RenderArgs {
   int has_proj = 0;                     // 1: proj replaces projection_matrix_from_intrinsics(K, H, W, 0.001, 100)
   double proj[16] = {0};
 };
+struct RenderPlan {
+  int S, strip_rows;                    // strips per hypothesis, rows per strip
+  size_t vbuf_bytes, count_bytes, list_bytes, total;
+};
+RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu);
 int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s);
 int launch_crop_window_tf(const float *poses, int N, const double *K, double crop_ratio, double diameter, int ow, int oh, float *tf,
                           float *bbox, hipStream_t s);

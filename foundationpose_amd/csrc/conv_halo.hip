@@ -7,9 +7,9 @@
 //   * brings the input rows it needs ONCE into LDS (the "halo band") and feeds all 9 taps from it: a tap shift is just a
 //     different LDS address per lane (+-1 pixel, +-1 row; taps outside the image select a zero chunk),
 //   * streams the 3 taps of one kernel row of weights at a time (128 co x 32 ci x 3 = 24 KB, double buffered) by LDS-DMA.
-// conv3x3_halo_dma_kernel: 8 waves, 512 px, band by LDS-DMA (double buffered), v_mfma_f32_32x32x16_f16.  Diagnostic builds
-// (make -B EXTRA=-DHALO_STAMP, never shipped) also hold the earlier register-staged form conv3x3_halo_kernel (4 or 8 waves,
-// FP_HALO_FORM=1 / FP_HALO_NPW) that carries the in-kernel cycle stamps; identical results.
+// conv3x3_halo_dma_kernel: 8 waves, 512 px, band by LDS-DMA (double buffered), v_mfma_f32_32x32x16_f16.  The diagnostic forms
+// (the earlier register-staged kernel that carries the in-kernel cycle stamps, the persistent-workgroup experiment) live in
+// diag/conv_halo_diag.inc and are compiled only by `make -B EXTRA=-DHALO_STAMP` (never shipped); identical results.
 // Epilogue: accumulators start at the bias; residual (staged through LDS) + ReLU (+ positional embedding) in fp32, one
 // rounding to fp16, LDS transpose, 16-byte row-contiguous NHWC stores.
 #include "common.h"
@@ -45,21 +45,6 @@ struct IC {
   static constexpr int value = V;
 };
 
-#ifdef HALO_STAMP      // the register-staged form exists in diagnostic builds only (it carries the in-kernel cycle stamps)
-template <int W, int TM>
-struct HaloCfg {
-  static constexpr int MAXSLOT = (W - 1 + TM - 1) / W + 1 + 2;     // input rows a TM-pixel run can touch (+1 above, +1 below)
-  static constexpr int HALO_CHUNKS = MAXSLOT * W * 4;              // 16-byte chunks (4 per pixel at 32 channels)
-  static constexpr int HALO_HALFS = (MAXSLOT * W + 2) * HL_PS + 8; // pixel p lives at index p+1; + one zero chunk
-  static constexpr int ZERO_OFF = (MAXSLOT * W + 2) * HL_PS;       // half offset of the zero chunk
-  static constexpr int halo_loads(int nth) { return (HALO_CHUNKS + nth - 1) / nth; }
-  static constexpr int WBUF_HALFS = 3 * HL_BM * HL_CK;             // one kernel row of taps
-  static constexpr int LDS_HALFS_MAIN = HALO_HALFS + 2 * WBUF_HALFS;
-  static constexpr int LDS_HALFS_EPI = TM * HL_SLD;
-  static constexpr int LDS_BYTES = 2 * (LDS_HALFS_MAIN > LDS_HALFS_EPI ? LDS_HALFS_MAIN : LDS_HALFS_EPI);
-};
-
-#endif
 // LDS-DMA issued from inline asm.  Through __builtin_amdgcn_global_load_lds the compiler marks a "flat access that may
 // touch LDS" as pending until the next full drain, and while that mark is up EVERY wait it inserts for an LDS fragment read
 // is s_waitcnt lgkmcnt(0) (and every barrier drains vmcnt(0)) - no LDS read can stay in flight under the MFMAs.  Hidden in
@@ -70,328 +55,12 @@ __device__ __forceinline__ void glds16(const f16 *sbase, unsigned voff_bytes, f1
   asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes), "s"(sbase), "s"(la) : "memory");
 }
 
-#ifdef HALO_STAMP
-// One workgroup tile: 2 NPW waves as 2 (cout halves) x NPW (pixel columns); each wave 64 co x 32*NT px (2 x NT accumulator
-// tiles), i.e. 128 couts x 32*NT*NPW pixels per workgroup.  NT = 4 -> main tiles, NT = 1 -> tail tiles.  The accumulation
-// order of every output element (chunk, ky, kx, k-step) does not depend on NT / NPW: the tile shape never changes a bit.
-template <int W, int NT, int NPW, bool RES, bool POST>
-__device__ __forceinline__ void halo_tile(const ConvArgs &p, const int m0, const int c0, f16 *lds, const int dbg) {
-  constexpr int TM = 32 * NT * NPW;
-  using C = HaloCfg<W, TM>;
-  constexpr int H = W;
-  constexpr int NWN = NPW;
-  constexpr int NTH = 128 * NPW;        // threads
-  constexpr int PXW = 32 * NT;          // pixels per wave
-  constexpr int HLOADS = C::halo_loads(NTH);
-  constexpr int WQ = 24 / (2 * NWN);    // weight DMA instructions per wave per group
-  STAMP(const unsigned long long t_entry = __builtin_amdgcn_s_memtime(); const unsigned long long r_entry = __builtin_amdgcn_s_memrealtime();)
-  f16 *halo = lds;
-  f16 *wbuf = lds + C::HALO_HALFS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NWN, wn = wave % NWN;
-  const int lr = lane & 31, lh = lane >> 5;
-  const int GR0 = m0 / W - 1;                       // global input row (n*H + iy) held by slot 0
-  const int total_rows = p.Nimg * H;
-  const int nchunk = p.Cin / HL_CK;
+#ifdef HALO_STAMP      // diagnostic builds only: the register-staged form that carries the in-kernel cycle stamps
+#define HALO_DIAG_SECTION 1
+#include "diag/conv_halo_diag.inc"
+#undef HALO_DIAG_SECTION
+#endif
 
-  // ---- per-lane B-fragment bases: pixel (slot(ky), ox) for the 4 pixel tiles of this wave ----
-  int pb[NT];         // LDS half-offset of the top-left tap; tap (ky,kx), k-step ks add the immediate ((ky*W+kx)*40 + ks*16)
-  unsigned vmask[NT]; // bit (ky*3+kx): tap inside the image
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    int m = m0 + wn * PXW + j * 32 + lr;
-    m = min(m, p.M - 1);
-    const int gr = m / W, ox = m - gr * W, oy = gr % H;
-    pb[j] = ((gr - GR0) * W + ox - W) * HL_PS + lh * 8;   // top-left tap (ky=0,kx=0) of this pixel, k-half lh
-    unsigned vm = 0;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int iy = oy + ky - 1, ix = ox + kx - 1;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) vm |= 1u << (ky * 3 + kx);
-      }
-    vmask[j] = vm;
-  }
-
-  // A-fragment bases (weights image is XOR-swizzled: chunk ^ ((co>>2)&3), identical for co and co+32)
-  int wa[2];
-  {
-    const int co = wm * 64 + lr;
-    wa[0] = co * 32 + ((lh ^ ((co >> 2) & 3)) * 8);
-    wa[1] = co * 32 + (((2 + lh) ^ ((co >> 2) & 3)) * 8);
-  }
-
-  // ---- halo staging: global -> registers (prefetch) -> LDS ----
-  // Load i of thread tid fetches 16-byte chunk (tid + NTH i): band pixel tid/4 + NTH/4 i, channel group tid%4.  Rows outside
-  // the tensor (above the first / below the last image, or past the slots in use) are CLAMPED to a valid pixel instead of
-  // skipped: what lands there is never read (those taps select the zero chunk through vmask), and every wave then
-  // issues exactly HLOADS loads - the counted vmcnt at ky=1 depends on that.  Offsets are 32-bit from the tensor base.
-  u32x4 hreg[HLOADS];
-  const int hpix0 = GR0 * W + (tid >> 2), hpix_max = total_rows * W - 1;
-  auto halo_load = [&](int cc, auto i0c, auto i1c) __attribute__((always_inline)) {     // loads I0 .. I1-1 of chunk cc (compile-time range: hreg stays in registers)
-    constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value < HLOADS ? decltype(i1c)::value : HLOADS;
-    int px0 = hpix0;
-    asm volatile("" : "+v"(px0));     // recompute the 32-bit offsets per chunk (hoisted, hipcc keeps 7 register pairs alive)
-    auto one = [&](auto ic) __attribute__((always_inline)) {
-      constexpr int i = decltype(ic)::value;
-      if constexpr (i >= I0 && i < I1) {
-        const int px = min(max(px0 + (NTH / 4) * i, 0), hpix_max);
-        hreg[i] = *reinterpret_cast<const u32x4 *>(p.in + (unsigned)(px * p.Cin + cc * HL_CK + (tid & 3) * 8));
-      }
-    };
-    one(IC<0>{}), one(IC<1>{}), one(IC<2>{}), one(IC<3>{}), one(IC<4>{}), one(IC<5>{}), one(IC<6>{});
-    static_assert(HLOADS <= 7, "extend the list");
-  };
-  auto halo_store = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < HLOADS; ++i) {
-      const int idx = tid + NTH * i;
-      const int pix = idx >> 2, ch = idx & 3;
-      if (idx < C::HALO_CHUNKS) *reinterpret_cast<u32x4 *>(&halo[(pix + 1) * HL_PS + ch * 8]) = hreg[i];
-    }
-  };
-  // ---- weights: one kernel row (3 taps) per group, LDS-DMA, lane-linear image with the swizzle on the SOURCE ----
-  // instruction q of wave w is 1-KB piece g = q*2*NPW + w of the 3 x 128 x 64-B image: tap kx = g/8, couts (g%8)*16 + lane/4,
-  // 16-byte channel group lane%4 (swizzled): the lane part of the source address is the same for every q, group and chunk
-  const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
-  auto wstage = [&](int cc, int ky, int buf, auto q0c, auto q1c) __attribute__((always_inline)) {     // DMA instructions Q0 .. Q1-1 of group (cc, ky)
-    constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
-#pragma unroll
-    for (int q = Q0; q < Q1; ++q) {
-      const int g0 = q * 2 * NPW;            // piece index without the wave part (wave < 2 NPW <= 8 never carries into g/8)
-      const f16 *sb = p.w + (size_t)(c0 + (g0 & 7) * 16) * p.Kpad + (ky * 3 + (g0 >> 3)) * p.Cin + cc * HL_CK;
-      glds16(sb, woff, wbuf + buf * C::WBUF_HALFS + (q * 2 * NWN + wave) * 512);
-    }
-  };
-
-  // accumulators start at the bias (fp32): a lane owns channels wm*64 + i*32 + rg*8 + lh*4 + (0..3) of its pixels
-  floatx16 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        acc[i][j][rg * 4 + 0] = bv.x;
-        acc[i][j][rg * 4 + 1] = bv.y;
-        acc[i][j][rg * 4 + 2] = bv.z;
-        acc[i][j][rg * 4 + 3] = bv.w;
-      }
-    }
-
-  if (tid < 1) *reinterpret_cast<u32x4 *>(&halo[C::ZERO_OFF]) = u32x4{0, 0, 0, 0};
-  halo_load(0, IC<0>{}, IC<HLOADS>{});
-  wstage(0, 0, 0, IC<0>{}, IC<WQ>{});
-  int g = 0;
-  STAMP(unsigned long long t_wait = 0; unsigned long long t_body = 0; unsigned long long t_top = 0; unsigned long long t_prev = __builtin_amdgcn_s_memtime();)
-  for (int cc = 0; cc < nchunk; ++cc) {
-    STAMP(unsigned long long tt0 = __builtin_amdgcn_s_memtime();)
-    __syncthreads();          // every wave is done reading the previous chunk's halo
-    halo_store();
-    STAMP(t_top += __builtin_amdgcn_s_memtime() - tt0;)
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky, ++g) {
-      const int buf = g & 1;
-      STAMP(unsigned long long ta = __builtin_amdgcn_s_memtime();)
-      // weights(g) must have landed and the halo stores must be visible.  The halo prefetch loads issued in
-      // group ky=0 are YOUNGER than the weights needed at ky=1, so a counted vmcnt leaves them in flight there
-      // (a __syncthreads() would drain them one group after issue).
-      if (ky == 1 && cc + 1 < nchunk) {
-        static_assert(HLOADS >= 2 && HLOADS <= 7, "add the vmcnt immediate for this tile");
-        if constexpr (HLOADS == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-        else if constexpr (HLOADS == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-        else if constexpr (HLOADS == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-        else if constexpr (HLOADS == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else if constexpr (HLOADS == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      STAMP(unsigned long long tb = __builtin_amdgcn_s_memtime(); t_wait += tb - ta;)
-      __builtin_amdgcn_sched_barrier(0);
-      // The next group's weights (into the other buffer) and, in group ky=0, the next chunk's halo (into registers) are
-      // requested from INSIDE the MFMA steps below - two DMAs after the first MFMA pair of steps 0..2, the halo loads in
-      // steps 3..5 - so their issue cycles (~60 per DMA) sit under running MFMAs instead of in front of the group.
-      // Program order stays "DMAs, then halo loads": the counted vmcnt at ky=1 relies on it.
-      int ncc = cc, nky = ky + 1;
-      if (nky == 3) {
-        nky = 0;
-        ncc = cc + 1;
-      }
-      // (diagnostic build only: dbg bit 0 / 1 switch the halo / weight reloads off - wrong results, timing experiments)
-      const bool more_w = ncc < nchunk STAMP(&& !(dbg & 2)), more_h = (ky == 0) && (cc + 1 < nchunk) STAMP(&& !(dbg & 1));
-      const f16 *wb = wbuf + buf * C::WBUF_HALFS;
-      // keep the per-tap border selects INSIDE the loop: hoisted, their 72 results would not fit the register file
-      unsigned vm[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        vm[j] = vmask[j];
-        asm volatile("" : "+v"(vm[j]));
-      }
-      // software pipeline over the 6 (kx, k-step) steps of this kernel row, in an order that needs only one spare
-      // weight-fragment pair: MFMAs go pixel-tile-major, so a pixel fragment is dead after two MFMAs and its register is
-      // reloaded for the NEXT step right away - every fragment is requested >= 6 MFMAs (192 cycles) before its first use.
-      // sched_barrier(0) pins that order; the waits the compiler inserts are then counted lgkmcnt(n), not lgkmcnt(0).
-      half8 af[2][2], bf[NT];
-      auto load_a = [&](int st, int set) __attribute__((always_inline)) {
-        const int kx = st >> 1, ks = st & 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const half8 *>(&wb[wa[ks] + i * (32 * 32) + kx * (HL_BM * HL_CK)]);
-      };
-      auto load_b = [&](int st, int j) __attribute__((always_inline)) {
-        const int kx = st >> 1, ks = st & 1;
-        const int imm = (ky * W + kx) * HL_PS + ks * 16;
-        const bool ok = (vm[j] >> (ky * 3 + kx)) & 1u;
-        const int base = ok ? pb[j] : (C::ZERO_OFF - imm);
-        bf[j] = *reinterpret_cast<const half8 *>(&halo[base + imm]);
-      };
-      load_a(0, 0);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) load_b(0, j);
-      __builtin_amdgcn_sched_barrier(0);
-      auto step = [&](auto stc) __attribute__((always_inline)) {
-        constexpr int st = decltype(stc)::value, cur = st & 1;
-        if (st + 1 < 6) load_a(st + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][0], bf[j], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][1], bf[j], acc[1][j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (st + 1 < 6) load_b(st + 1, j);
-          if (j == 0) {
-            if constexpr (st < 3) {
-              if (more_w) wstage(ncc, nky, buf ^ 1, IC<(WQ / 3) * st>{}, IC<(WQ / 3) * (st + 1)>{});
-            } else {
-              constexpr int HP = (HLOADS + 2) / 3;
-              if (more_h) halo_load(cc + 1, IC<(st - 3) * HP>{}, IC<(st - 3) * HP + HP>{});
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      };
-      step(IC<0>{});
-      step(IC<1>{});
-      step(IC<2>{});
-      step(IC<3>{});
-      step(IC<4>{});
-      step(IC<5>{});
-      STAMP(t_body += __builtin_amdgcn_s_memtime() - tb;)
-    }
-  }
-  STAMP(const unsigned long long t_loop_end = __builtin_amdgcn_s_memtime();)
-
-  // ---------------- epilogue ----------------
-  // RES / POST are compile-time (a runtime flag costs three branches per register quad, ~100 per wave), ReLU is a
-  // branch-free max against 0 or -inf.  The residual tile (16 x 16 B per thread, row-contiguous) is requested in ONE batch
-  // and before the barrier - the loop's fragment / halo registers are dead here - so it travels while the slower waves
-  // finish their MFMAs.
-  f16 *stage = lds;   // [TM px][HL_SLD]
-  constexpr int NRES = TM * 16 / NTH;
-  u32x4 rv[NRES];
-  if constexpr (RES) {
-#pragma unroll
-    for (int u = 0; u < NRES; ++u) {
-      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
-      const int m = min(m0 + px, p.M - 1);      // unconditional (clamped) load: a guarded one makes hipcc wait per element
-      rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
-    }
-  }
-  const float lo = p.relu ? 0.f : -__builtin_inff();
-  STAMP(const unsigned long long t_e0 = __builtin_amdgcn_s_memtime();)
-  __syncthreads();          // every wave is done with the halo / weight images: the staging tile may overwrite them
-  STAMP(const unsigned long long t_e1 = __builtin_amdgcn_s_memtime();)
-  if constexpr (RES) {
-#pragma unroll
-    for (int u = 0; u < NRES; ++u) {
-      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
-      *reinterpret_cast<u32x4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
-    }
-    __syncthreads();
-  }
-  STAMP(const unsigned long long t_e2 = __builtin_amdgcn_s_memtime();)
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int pxl = wn * PXW + j * 32 + lr;
-    float4 pvs[2][4];
-    if constexpr (POST) {
-      const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
-    }
-    // the 8 staged residual quads of this pixel are read in one go (a read -> write pair per quad serialises 32 LDS latencies)
-    half4 rq[2][4];
-    if constexpr (RES) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) rq[i][rg] = *reinterpret_cast<const half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 32 + rg * 8 + lh * 4]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int col = wm * 64 + i * 32 + rg * 8 + lh * 4;   // channel within the 128-wide tile
-        float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
-        if constexpr (RES) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][rg][e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
-        if constexpr (POST) {
-          const float4 pv = pvs[i][rg];
-          v[0] += pv.x;
-          v[1] += pv.y;
-          v[2] += pv.z;
-          v[3] += pv.w;
-        }
-        half4 hv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
-        *reinterpret_cast<half4 *>(&stage[pxl * HL_SLD + col]) = hv;
-      }
-    }
-  }
-  STAMP(const unsigned long long t_e3 = __builtin_amdgcn_s_memtime();)
-  __syncthreads();
-  STAMP(const unsigned long long t_e4 = __builtin_amdgcn_s_memtime();)
-  constexpr int NOUT = TM * 16 / NTH, OB = NOUT < 8 ? NOUT : 8;
-#pragma unroll
-  for (int i0 = 0; i0 < NOUT; i0 += OB) {
-    u32x4 ov[OB];
-#pragma unroll
-    for (int u = 0; u < OB; ++u) {
-      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
-      ov[u] = *reinterpret_cast<const u32x4 *>(&stage[px * HL_SLD + c16 * 8]);
-    }
-#pragma unroll
-    for (int u = 0; u < OB; ++u) {
-      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
-      const int m = m0 + px;
-      if (m < p.M) {
-        const bool hi = m >= p.split_m;
-        const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
-        const int coff = hi ? p.coff_hi : 0;
-        *reinterpret_cast<u32x4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
-      }
-    }
-  }
-  STAMP(if (lane == 0 && blockIdx.x < 4096) {
-    unsigned long long *o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
-    if (dbg & 4) { t_wait = ((t_e0 - t_loop_end) << 32) | (t_e1 - t_e0); t_body = ((t_e2 - t_e1) << 32) | (t_e3 - t_e2); t_top = (t_e4 - t_e3); }
-    o[0] = t_wait; o[1] = t_body; o[2] = t_top | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);   /* HW_ID in the high half */ o[3] = t_loop_end - t_prev; o[4] = t_prev - t_entry;
-    o[5] = __builtin_amdgcn_s_memtime() - t_loop_end; o[6] = r_entry; o[7] = __builtin_amdgcn_s_memrealtime();
-  })
-}
-
-#endif   // HALO_STAMP
 // ------------------------------------------------------------------------------------------------------------------------
 // DEFAULT FORM.  8-wave tile (512 px x 128 co, one workgroup per CU) with the halo band staged by LDS-DMA as well, double
 // buffered:
@@ -726,301 +395,11 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
   })
 }
 
-#ifdef HALO_STAMP
-// ------------------------------------------------------------------------------------------------------------------------
-// PERSISTENT FORM of the 8-wave tile for launches of two or more full rounds (diagnostic builds only, FP_HALO_PERSIST=1: measured
-// equal to the per-tile form inside a step - DESIGN.md section 6 - and kept as the record of that experiment; bit-identical results): one workgroup per CU walks `rounds` 512-pixel
-// tiles (tile r of workgroup w is logical tile r * n_wg + xcd_remap(w)), and the group stream never stops at a tile boundary:
-//   * the band of the next tile's chunk 0 is requested in the last chunk's ky = 0 group, its first weight group in the last
-//     ky = 2 group - exactly where the next chunk's / next group's DMAs go inside a tile - so a tile has NO prologue;
-//   * the epilogue needs one barrier and no buffer of its own: each wave stages its 128 pixels x 64 channels through a slice of
-//     the band buffer the last chunk has just released (residual rows in, fp32 add / ReLU as in the staged epilogue, rows out:
-//     16-byte loads and stores of 128 contiguous bytes per pixel), and its stores drain under the next tile's first group (a
-//     counted vmcnt leaves them in flight: loads, stores and LDS-DMA retire in issue order).  A first form that stored 8 bytes
-//     per (pixel, 4 channels) straight from the accumulators - 32 cache lines per instruction - was 18 % SLOWER than the
-//     per-tile kernel (375 against 317 us at C = 128) while the same loop without any epilogue traffic ran 234 us.
-// The arithmetic of an output element is that of halo_tile_dma: results are bit-identical.
-template <int W, bool RES, bool POST>
-__device__ __forceinline__ void halo_persist(const ConvArgs &p, const int n_wg, const int rounds, f16 *lds) {
-  constexpr int NT = 4, NPW = 4, TM = 512;
-  using C = HaloCfgD<W, TM>;
-  constexpr int H = W;
-  constexpr int PXW = 32 * NT;
-  constexpr int HQ = C::HQ;
-  constexpr int WQ = 24 / (2 * NPW);
-  constexpr int NST = NT * 4;           // epilogue stores per wave and tile
-  f16 *wbuf = lds + C::WBUF_OFF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / NPW, wn = wave % NPW;
-  const int lr = lane & 31, lh = lane >> 5;
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-  const int total_rows = p.Nimg * H;
-  const int nchunk = p.Cin / HL_CK;
-  const int n_ct = p.Cout / HL_BM;
-  const int wslot = xcd_remap(blockIdx.x, n_wg);
-  const int hpix_max = total_rows * W - 1;
-
-  int wa[2];
-  {
-    const int co = wm * 64 + lr;
-    wa[0] = co * 32 + ((lh ^ ((co >> 2) & 3)) * 8);
-    wa[1] = co * 32 + (((2 + lh) ^ ((co >> 2) & 3)) * 8);
-  }
-  auto halo_dma = [&](int gr0, int cc, int hb, auto hc) __attribute__((always_inline)) {
-    constexpr int h = decltype(hc)::value;
-    int l4 = lane >> 2;
-    asm volatile("" : "+v"(l4));
-    const int P = (h * 8 + wave) * 16 + l4;
-    const int c = (lane & 3) ^ ((P >> 2) & 3);
-    const int gp = min(max(gr0 * W + P - 1, 0), hpix_max);
-    const unsigned off = (unsigned)(gp * p.Cin + cc * HL_CK + c * 8) * 2u;
-    glds16(p.in, off, lds + hb * C::HBUF_HALFS + (h * 8 + wave) * 512);
-  };
-  const unsigned woff = (unsigned)(((wave * 16 + (lane >> 2)) * p.Kpad + (((lane & 3) ^ ((lane >> 4) & 3)) * 8)) * 2);
-  auto wstage = [&](int c0w, int cc, int ky, int buf, auto q0c, auto q1c) __attribute__((always_inline)) {
-    constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
-#pragma unroll
-    for (int q = Q0; q < Q1; ++q) {
-      const int g0 = q * 2 * NPW;
-      const f16 *sb = p.w + (size_t)(c0w + (g0 & 7) * 16) * p.Kpad + (ky * 3 + (g0 >> 3)) * p.Cin + cc * HL_CK;
-      glds16(sb, woff, wbuf + buf * C::WBUF_HALFS + (q * 2 * NPW + wave) * 512);
-    }
-  };
-  auto tile_of = [&](int r, int *m0, int *c0) __attribute__((always_inline)) {
-    const int L = r * n_wg + wslot;
-    *m0 = (L / n_ct) * TM;
-    *c0 = (L % n_ct) * HL_BM;
-  };
-
-  if (tid < 1) *reinterpret_cast<u32x4 *>(&lds[C::ZERO_OFF]) = u32x4{0, 0, 0, 0};
-  int m0, c0;
-  tile_of(0, &m0, &c0);
-  {
-    const int gr0 = m0 / W - 1;
-    auto all = [&](auto hc) __attribute__((always_inline)) {
-      if constexpr (decltype(hc)::value < HQ) halo_dma(gr0, 0, 0, hc);
-    };
-    all(IC<0>{}), all(IC<1>{}), all(IC<2>{}), all(IC<3>{}), all(IC<4>{}), all(IC<5>{}), all(IC<6>{}), all(IC<7>{});
-  }
-  wstage(c0, 0, 0, 0, IC<0>{}, IC<WQ>{});
-  int g = 0;
-  bool prev_full = false;               // the previous tile of this workgroup issued exactly NST stores per wave
-
-  for (int r = 0; r < rounds; ++r) {
-    const int GR0 = m0 / W - 1;
-    const bool has_next = r + 1 < rounds;
-    int m0n = 0, c0n = 0;
-    if (has_next) tile_of(r + 1, &m0n, &c0n);
-    const int GR0n = m0n / W - 1;
-    // ---- per-tile lane constants (as in halo_tile_dma) ----
-    const int pb = m0 + wn * PXW + lr - GR0 * W - W;
-    unsigned vmp[(NT + 2) / 3];
-#pragma unroll
-    for (int t = 0; t < (NT + 2) / 3; ++t) vmp[t] = 0;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int m = min(m0 + wn * PXW + j * 32 + lr, p.M - 1);
-      const int gr = m / W, ox = m - gr * W, oy = gr % H;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int iy = oy + ky - 1, ix = ox + kx - 1;
-          if (iy >= 0 && iy < H && ix >= 0 && ix < W) vmp[j / 3] |= 1u << ((j % 3) * 9 + ky * 3 + kx);
-        }
-    }
-    floatx16 acc[2][NT];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j][rg * 4 + 0] = bv.x;
-          acc[i][j][rg * 4 + 1] = bv.y;
-          acc[i][j][rg * 4 + 2] = bv.z;
-          acc[i][j][rg * 4 + 3] = bv.w;
-        }
-      }
-
-    for (int cc = 0; cc < nchunk; ++cc) {
-      const f16 *halo = lds + (cc & 1) * C::HBUF_HALFS;
-      const bool band_next = (cc + 1 < nchunk) || has_next;      // a band is requested in this chunk's ky = 0 group
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky, ++g) {
-        const int buf = g & 1;
-        // weights(g) - and at ky = 0 the band of this chunk - must have landed.  Younger operations that may stay in flight:
-        // at ky = 1 the HQ band DMAs requested one group ago; at the first group of a tile the NST stores of the previous
-        // tile's epilogue (issued after this group's weights and band were requested).
-        if (ky == 1 && band_next) {
-          static_assert(HQ >= 2 && HQ <= 6, "add the vmcnt immediate for this tile");
-          if constexpr (HQ == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-          else if constexpr (HQ == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-          else if constexpr (HQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-          else if constexpr (HQ == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        } else if (ky == 0 && cc == 0 && prev_full) {
-          // behind this group's band and weight requests the previous epilogue issued its residual loads (consumed, so
-          // complete) and then NST stores: the stores may stay in flight
-          static_assert(NST == 16, "the immediates below");
-          asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        int ncc = cc, nky = ky + 1, c0w = c0;
-        bool more_w = true;
-        if (nky == 3) {
-          nky = 0;
-          ncc = cc + 1;
-          if (ncc == nchunk) {          // the next group is the first one of the next tile
-            ncc = 0;
-            c0w = c0n;
-            more_w = has_next;
-          }
-        }
-        const bool more_h = (ky == 0) && band_next;
-        const int hcc = cc + 1 < nchunk ? cc + 1 : 0, hgr0 = cc + 1 < nchunk ? GR0 : GR0n;
-        const f16 *wb = wbuf + buf * C::WBUF_HALFS;
-        unsigned vm[(NT + 2) / 3];
-#pragma unroll
-        for (int t = 0; t < (NT + 2) / 3; ++t) {
-          vm[t] = vmp[t];
-          asm volatile("" : "+v"(vm[t]));
-        }
-        constexpr int NV = 6 * NT, BD = 4;
-        half8 af[2][2], bf[BD];
-        int tapb[3][2];
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int Pt = pb + ky * W + kx, sw = (Pt >> 2) & 3;
-          tapb[kx][0] = Pt * 32 + ((lh ^ sw) * 8);
-          tapb[kx][1] = Pt * 32 + (((2 + lh) ^ sw) * 8);
-        }
-        auto load_a = [&](int st, int set) __attribute__((always_inline)) {
-          const int kx = st >> 1, ks = st & 1;
-#pragma unroll
-          for (int i = 0; i < 2; ++i) af[set][i] = *reinterpret_cast<const half8 *>(&wb[wa[ks] + i * (32 * 32) + kx * (HL_BM * HL_CK)]);
-        };
-        auto load_b = [&](auto tc) __attribute__((always_inline)) {
-          constexpr int t = decltype(tc)::value, st = t / NT, j = t % NT, kx = st >> 1, ks = st & 1;
-          constexpr int imm = j * 32 * 32;
-          const bool ok = (vm[j / 3] >> ((j % 3) * 9 + ky * 3 + kx)) & 1u;
-          const int base = ok ? tapb[kx][ks] : (C::ZERO_OFF - (cc & 1) * C::HBUF_HALFS - imm);
-          bf[t % BD] = *reinterpret_cast<const half8 *>(&halo[base + imm]);
-        };
-        load_a(0, 0);
-        load_b(IC<0>{});
-        load_b(IC<1>{});
-        load_b(IC<2>{});
-        load_b(IC<3>{});
-        __builtin_amdgcn_sched_barrier(0);
-        auto visit = [&](auto tc) __attribute__((always_inline)) {
-          constexpr int t = decltype(tc)::value, st = t / NT, j = t % NT, cur = st & 1;
-          if constexpr (j == 0 && st + 1 < 6) {
-            load_a(st + 1, cur ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][0], bf[t % BD], acc[0][j], 0, 0, 0);
-          acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[cur][1], bf[t % BD], acc[1][j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (t + BD < NV) load_b(IC<t + BD>{});
-          static_assert(WQ + HQ <= NV, "DMA issue slots");
-          if constexpr (t < WQ) {
-            if (more_w) wstage(c0w, ncc, nky, buf ^ 1, IC<t>{}, IC<t + 1>{});
-          } else if constexpr (t - WQ < HQ) {
-            if (more_h) halo_dma(hgr0, hcc, (cc + 1) & 1, IC<t - WQ>{});
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        };
-#define V4(a) visit(IC<(a)>{}); visit(IC<(a) + 1>{}); visit(IC<(a) + 2>{}); visit(IC<(a) + 3>{});
-        V4(0) V4(4) V4(8) V4(12) V4(16) V4(20)
-#undef V4
-      }
-    }
-
-    // ---------------- epilogue: per-wave staging in the band buffer the last chunk has just released ----------------
-    // (an even chunk count: the last chunk read buffer 1, the next tile's chunk 0 sits in buffer 0 and its chunk 1 is requested
-    // only behind the next group's barrier.)  One barrier, so that no wave still reads buffer 1; then every wave turns its 128
-    // pixels x 64 channels around on its own: residual rows in (16-byte loads, 128 bytes per pixel), fp32 add / ReLU exactly as
-    // the staged epilogue of halo_tile_dma does, rows out (16-byte stores).
-    const int rpx = lane >> 3, c16 = lane & 7;              // row form: instruction u covers pixels 8u .. 8u+7, 8 lanes x 16 B each
-    u32x4 rv[RES ? NT : 1][4];
-    if constexpr (RES) {
-      // all 16 residual row segments of the wave are requested at once, ahead of the barrier (the fragment registers of the
-      // main loop are dead here): one memory round trip per tile instead of one per 32-pixel tile
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int mr = min(m0 + wn * PXW + j * 32 + u * 8 + rpx, p.M - 1);
-          rv[j][u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)mr * p.Cout + c0 + wm * 64 + c16 * 8);
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      constexpr int PLD = 72;                               // halfs per staged pixel (64 channels + 8 pad = 144 B)
-      static_assert(8 * 32 * PLD <= C::HBUF_HALFS, "the per-wave staging slices fit one band buffer");
-      f16 *stage = lds + C::HBUF_HALFS + wave * (32 * PLD);
-      const float lo = p.relu ? 0.f : -__builtin_inff();
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int mt = m0 + wn * PXW + j * 32;              // first pixel of this 32-pixel tile
-        if constexpr (RES) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) *reinterpret_cast<u32x4 *>(&stage[(u * 8 + rpx) * PLD + c16 * 8]) = rv[j][u];
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
-            f16 *sp = &stage[lr * PLD + i * 32 + rg * 8 + lh * 4];
-            if constexpr (RES) {
-              const half4 rq = *reinterpret_cast<const half4 *>(sp);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)rq[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
-            half4 hv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
-            *reinterpret_cast<half4 *>(sp) = hv;
-          }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        u32x4 ov[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ov[u] = *reinterpret_cast<const u32x4 *>(&stage[(u * 8 + rpx) * PLD + c16 * 8]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int mr = mt + u * 8 + rpx, mc = min(mr, p.M - 1);
-          const bool hi = mc >= p.split_m;
-          f16 *o = (f16 *)p.out + (hi ? (long long)(mc - p.split_m) : (long long)mc) * p.out_ld + (hi ? p.coff_hi : 0) + c0 + wm * 64 + c16 * 8;
-          if (mr < p.M) *reinterpret_cast<u32x4 *>(o) = ov[u];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are in registers before the next tile's values overwrite them
-      }
-    }
-    prev_full = m0 + TM <= p.M;
-    m0 = m0n;
-    c0 = c0n;
-  }
-}
-
-template <int W, bool RES, bool POST>
-__global__ __launch_bounds__(512, 1) void conv3x3_halo_persist_kernel(ConvArgs p, int rounds) {
-  extern __shared__ __attribute__((aligned(16))) f16 lds[];
-  halo_persist<W, RES, POST>(p, gridDim.x, rounds, lds);
-}
-
-#endif   // HALO_STAMP (persistent form)
+#ifdef HALO_STAMP      // diagnostic builds only: the persistent-workgroup form (FP_HALO_PERSIST=1)
+#define HALO_DIAG_SECTION 2
+#include "diag/conv_halo_diag.inc"
+#undef HALO_DIAG_SECTION
+#endif
 
 template <int W, bool RES, bool POST>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, int n_main, int tile0) {
@@ -1081,34 +460,6 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p) {
   *reinterpret_cast<half4 *>((f16 *)p.out + orow * p.out_ld + (hi ? p.coff_hi : 0) + c) = hv;
 }
 
-#ifdef HALO_STAMP
-// Grid = n_main workgroups of 128 NPW px x 128 co, then n_tail4 workgroups of 32 NPW px x 128 co covering the LAST main-size
-// tiles cut in four.  A launch has (workgroups per CU) x 256 slots; at N=252 every layer of the network has 3150 or 1576
-// 256-pixel tiles, i.e. a last round that is 8-15 % full - cutting only that remainder into quarters lets the round end
-// after a fraction of the time.  (Cutting every tile would cost the big tile's operand reuse.)
-//
-// NPW = 4 (8 waves, 512 px x 128 co, ONE workgroup per CU) is the default: every byte of the weight image that streams
-// through LDS-DMA then feeds twice as many MFMAs as with two independent 256-pixel workgroups per CU, and that stream
-// (not the MFMA pipe) is what bounds the 4-wave form: with the weight DMA switched off it runs 30 % faster, with the
-// halo loads switched off 6 %.
-template <int W, int NPW, bool RES, bool POST>
-__global__ __launch_bounds__(128 * NPW, NPW == 2 ? 2 : 1) void conv3x3_halo_kernel(ConvArgs p, int n_main, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) f16 lds[];
-  constexpr int TMM = 128 * NPW;
-  const int n_ct = p.Cout / HL_BM;
-  if ((int)blockIdx.x < n_main) {
-    const int L = xcd_remap(blockIdx.x, n_main);   // consecutive L = cout tiles of one pixel tile, then the next pixel tile
-    halo_tile<W, 4, NPW, RES, POST>(p, (L / n_ct) * TMM, (L % n_ct) * HL_BM, lds, dbg);
-  } else {
-    const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
-    const int L = n_main + (t >> 2);
-    const int m0 = (L / n_ct) * TMM + (t & 3) * (TMM / 4);
-    if (m0 >= p.M) return;
-    halo_tile<W, 1, NPW, RES, POST>(p, m0, (L % n_ct) * HL_BM, lds, dbg);
-  }
-}
-
-#endif   // HALO_STAMP
 
 bool conv_halo_supported(const ConvArgs &a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H == a.W && (a.W == 40 || a.W == 20) && a.Cin % HL_CK == 0 &&
@@ -1143,42 +494,11 @@ void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
   }
 }
 
-#ifdef HALO_STAMP
-template <int W, int NPW, bool RES, bool POST>
-static int launch_halo_w(const ConvArgs &a, hipStream_t s) {
-  constexpr int TMM = 128 * NPW;
-  using C = HaloCfg<W, TMM>;
-  static bool attr_set = false;
-  static int slots = 512;
-#ifdef HALO_STAMP
-  static int dbg = getenv("FP_HALO_DBG") ? atoi(getenv("FP_HALO_DBG")) : 0;   // diagnostic build: 1 = no halo reloads, 2 = no weight reloads, 4 = epilogue stamps
-#else
-  const int dbg = 0;
+#ifdef HALO_STAMP      // diagnostic builds only: entry points and launchers of the forms above
+#define HALO_DIAG_SECTION 3
+#include "diag/conv_halo_diag.inc"
+#undef HALO_DIAG_SECTION
 #endif
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_kernel<W, NPW, RES, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    int dev = 0, cus = 256;
-    FP_CHECK_HIP(hipGetDevice(&dev));
-    FP_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    slots = (NPW == 2 ? 2 : 1) * cus;
-    attr_set = true;
-  }
-  const int n_tiles = ((a.M + TMM - 1) / TMM) * (a.Cout / HL_BM);
-  int n_main, n_tail4;
-  halo_split(n_tiles, slots, &n_main, &n_tail4);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<W, NPW, RES, POST>), dim3(n_main + n_tail4), dim3(128 * NPW), C::LDS_BYTES, s, a, n_main, dbg);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-
-template <int W, int NPW>
-static int launch_halo_flags(const ConvArgs &a, hipStream_t s) {
-  if (a.post_add) return a.res ? launch_halo_w<W, NPW, true, true>(a, s) : launch_halo_w<W, NPW, false, true>(a, s);
-  return a.res ? launch_halo_w<W, NPW, true, false>(a, s) : launch_halo_w<W, NPW, false, false>(a, s);
-}
-
-#endif   // HALO_STAMP
 
 template <int W, bool RES, bool POST>
 static int launch_halo_dma(const ConvArgs &a, hipStream_t s) {
@@ -1198,22 +518,7 @@ static int launch_halo_dma(const ConvArgs &a, hipStream_t s) {
   halo_split(n_tiles, slots, &n_main, &n_tail4);
   int tile0 = 0;
 #ifdef HALO_STAMP
-  // diagnostic builds, FP_HALO_PERSIST=1: two or more whole rounds go to the persistent form, the remainder - whole tiles or
-  // quarter tiles, as halo_split decided - follows as a launch of the per-tile form
-  static const bool persist_on = getenv("FP_HALO_PERSIST") && atoi(getenv("FP_HALO_PERSIST")) == 1;
-  static bool attr_p = false;
-  const int rounds = n_main / slots;
-  if constexpr (!POST) {            // (the positional-embedding layer stays on the per-tile form: its fp32 rows do not fit the staging slices)
-    if (persist_on && rounds >= 2 && (a.Cin / HL_CK) % 2 == 0) {          // (the band buffers alternate per chunk across tiles: an even chunk count)
-      if (!attr_p) {
-        FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_persist_kernel<W, RES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_p = true;
-      }
-      hipLaunchKernelGGL((conv3x3_halo_persist_kernel<W, RES, false>), dim3(slots), dim3(512), C::LDS_BYTES, s, a, rounds);
-      tile0 = rounds * slots;
-      n_main -= tile0;
-    }
-  }
+  FP_TRY((diag_launch_persist<W, RES, POST>(a, slots, C::LDS_BYTES, &n_main, &tile0, s)));
 #endif
   if (n_main + n_tail4 > 0)
     hipLaunchKernelGGL((conv3x3_halo_dma_kernel<W, RES, POST>), dim3(n_main + n_tail4), dim3(512), C::LDS_BYTES, s, a, n_main, tile0);

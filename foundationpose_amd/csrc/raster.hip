@@ -1,14 +1,20 @@
 // Batched pose-hypothesis rasteriser for gfx950 (replaces nvdiffrast in src/Utils.py:133-219) and the
 // crop-window transform (src/Utils.py:577-621).
 //
-// Regime: a 160x160 crop of a ~16k-face mesh => triangles are 1-3 pixels ("micro-polygons").  A
-// sort-middle tile binner would spend its time binning; instead the FRAMEBUFFER lives in LDS and the
-// triangles stream through the CU:
-//   one workgroup = one hypothesis x one horizontal strip of the crop (80 rows x 160 px x 8 B = 100 KiB
-//   of the 160 KiB LDS); every lane sets up whole triangles (vertex transform as fmaf chains, 1/16-px
-//   snapping, 64-bit integer edge functions, top-left rule) and resolves visibility with one
-//   ds_min_u64 per covered pixel on the packed key (ordered z/w : 32 | face id : 32) - nearest wins,
-//   ties go to the lower face id, independent of lane scheduling => bit-reproducible.
+// Regime: a 160x160 crop of a ~16k-face mesh => triangles are 1-3 pixels ("micro-polygons"), and about half of them cover
+// no pixel centre at all.  Three launches per batch of hypotheses:
+//   1. xform_vertices_kernel: every (hypothesis, vertex) transformed ONCE (clip matrix in float64, 1/16-px snapping) -> 16 B;
+//   2. bin_faces_kernel: one thread per (hypothesis, face) computes the face's pixel range with the rasteriser's own integer
+//      arithmetic, drops faces that cover no pixel centre of the crop (and zero-area ones), and appends the face id to the
+//      list of every horizontal STRIP of the crop its rows touch (wave-aggregated atomic append; the order inside a list is
+//      not deterministic and does not matter: visibility below is a minimum over (depth, face id) keys);
+//   3. render_kernel: one workgroup = one hypothesis x one strip (40 rows x 160 px x 8 B = 50 KiB of LDS at >= 64 hypotheses,
+//      thinner strips for fewer; several workgroups per CU).  The strip's FRAMEBUFFER lives in LDS; the lanes walk the strip's
+//      face list (whole triangles per lane: 64-bit / 32-bit integer edge functions, top-left rule) and resolve visibility with
+//      one ds_min_u64 per covered pixel on the packed key (ordered z/w : 32 | face id : 32) - nearest wins, ties go to the
+//      lower face id, independent of lane scheduling and list order => bit-reproducible.
+//      (Until round 3 a workgroup walked ALL faces of the mesh for each of its two 80-row strips: 200 us per 252-hypothesis
+//      launch, 65 us of a workgroup's 110 in the triangle loop.)
 //   A second pass resolves each pixel: perspective-correct barycentrics, attribute interpolation,
 //   shading, and either fp32 channels-last maps (API parity with nvdiffrast_render) or the fused
 //   network-ready fp16 NHWC8 tensor (rgb, (xyz-t)*2/diam with invalid masking; h5_dataset.py:92-99),
@@ -17,7 +23,13 @@
 // The arithmetic is mirrored 1:1 by oracle/raster_c.c.
 #include "common.h"
 
-#define RB_THREADS 1024
+#define RB_THREADS 512
+#ifndef RB_MINW
+#define RB_MINW 4     // waves per SIMD the register budget is held to: two 8-wave workgroups per CU
+#endif
+#ifndef RB_FLY
+#define RB_FLY 2      // triangles in flight per thread in the list walk (4 need 159 VGPRs: one workgroup per CU instead of two)
+#endif
 
 __device__ __forceinline__ unsigned ordered_key(float z) {
   unsigned b = __float_as_uint(z);
@@ -154,10 +166,12 @@ __device__ void clip_matrix(const RenderArgs &a, int b, const float *pose, float
 // Vertex pre-pass for the fused network path: every hypothesis' vertices transformed ONCE (the triangle loop of render_kernel
 // otherwise re-transforms a vertex for each of its ~6 triangles, in each strip, behind two dependent global round trips).
 // One int4 per vertex: X (INT_MIN = behind the camera / off range), Y, bits of z/w, bits of w - exactly xform_vertex's values.
-__global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 *__restrict__ vout) {
+__global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 *__restrict__ vout, int *__restrict__ count, int S) {
   __shared__ float sM[16];
   const int b = blockIdx.y;
   if (threadIdx.x == 0) clip_matrix(a, b, a.poses + (size_t)b * 16, sM);
+  if (blockIdx.x == 0)                  // the strip lists of this hypothesis start empty (bin_faces_kernel runs behind this launch)
+    for (int q = threadIdx.x; q < S; q += 256) count[(size_t)b * S + q] = 0;
   __syncthreads();
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= a.mesh.V) return;
@@ -168,12 +182,54 @@ __global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 
   vout[(size_t)b * a.mesh.V + v] = make_int4(o.ok ? o.X : (int)0x80000000, o.Y, __float_as_int(o.zn), __float_as_int(o.w));
 }
 
-template <int MODE, bool VB>
-__global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int strip_rows, int n_strips, const int4 *__restrict__ vbuf) {
+
+// Face lists per (hypothesis, strip).  A face is dropped here exactly when raster_tri() below would return without touching a
+// pixel for EVERY strip (pixel range empty after clamping to the crop, or zero area) - the same integers, so the images are
+// bit-identical to the unbinned walk; a face that straddles the camera plane cannot be bounded cheaply and goes to every strip.
+__global__ __launch_bounds__(256) void bin_faces_kernel(RenderArgs a, const int4 *__restrict__ vbuf, int *__restrict__ count,
+                                                        int *__restrict__ list, int S, int strip_rows) {
+  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const MeshDev &m = a.mesh;
+  int s0 = 1, s1 = 0;                                   // strips [s0, s1] (empty)
+  if (t < m.F) {
+    const int4 *vb = vbuf + (size_t)b * m.V;
+    const int4 q0 = vb[m.faces[t * 3]], q1 = vb[m.faces[t * 3 + 1]], q2 = vb[m.faces[t * 3 + 2]];
+    const bool ok0 = q0.x != (int)0x80000000, ok1 = q1.x != (int)0x80000000, ok2 = q2.x != (int)0x80000000;
+    if (!(ok0 && ok1 && ok2)) {
+      if (__int_as_float(q0.w) > 0.f || __int_as_float(q1.w) > 0.f || __int_as_float(q2.w) > 0.f) s0 = 0, s1 = S - 1;
+    } else {
+      const long long X0 = q0.x, Y0 = q0.y, X1 = q1.x, Y1 = q1.y, X2 = q2.x, Y2 = q2.y;
+      const long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+      const int xmin = min(q0.x, min(q1.x, q2.x)), xmax = max(q0.x, max(q1.x, q2.x));
+      const int ymin = min(q0.y, min(q1.y, q2.y)), ymax = max(q0.y, max(q1.y, q2.y));
+      const int ia = max((xmin - 8 + 15) >> 4, 0), ib = min((xmax - 8) >> 4, a.Wo - 1);
+      const int ja = max((ymin - 8 + 15) >> 4, 0), jb = min((ymax - 8) >> 4, a.Ho - 1);
+      if (area != 0 && ia <= ib && ja <= jb) s0 = ja / strip_rows, s1 = jb / strip_rows;
+    }
+  }
+  if (S <= 16) {                                        // one atomic per wave and strip
+    for (int s = 0; s < S; ++s) {
+      const bool in = s >= s0 && s <= s1;
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(in);
+      if (mk == 0) continue;
+      int base = 0;
+      if (lane == __builtin_ctzll(mk)) base = atomicAdd(&count[(size_t)b * S + s], __builtin_popcountll(mk));
+      base = __shfl(base, __builtin_ctzll(mk));
+      if (in) list[((size_t)b * S + s) * m.F + base + __builtin_popcountll(mk & ((1ull << lane) - 1))] = t;
+    }
+  } else {
+    for (int s = s0; s <= s1; ++s) list[((size_t)b * S + s) * m.F + atomicAdd(&count[(size_t)b * S + s], 1)] = t;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(RB_THREADS, RB_MINW) void render_kernel(RenderArgs a, int strip_rows, int n_strips, const int4 *__restrict__ vbuf,
+                                                                 const int *__restrict__ count, const int *__restrict__ list) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];
   __shared__ float sM[16];
   __shared__ float sP[12];
-  const int b = blockIdx.x / n_strips, strip = blockIdx.x % n_strips;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);          // the strips of one hypothesis share an XCD's L2 (vertices, lists)
+  const int b = L / n_strips, strip = L % n_strips;
   const int Ho = a.Ho, Wo = a.Wo;
   const int row0 = strip * strip_rows;  // GL (bottom-up) rows [row0, row1)
   const int row1 = min(Ho, row0 + strip_rows);
@@ -187,14 +243,12 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   for (int i = threadIdx.x; i < npix; i += RB_THREADS) zbuf[i] = ~0ull;
   __syncthreads();
 
-  float M[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) M[i] = sM[i];
+  // (the clip matrix stays in LDS: only triangles that straddle the camera plane read it)
+  const float *M = sM;
   const float hw = 0.5f * (float)Wo, hh = 0.5f * (float)Ho;
   const MeshDev &m = a.mesh;
-  const int4 *vb = VB ? vbuf + (size_t)b * m.V : nullptr;
-  auto vertex = [&](int i) -> Vtx {          // with the pre-pass: one 16-byte load instead of 3 loads + the transform
-    if (!VB) return xform_vertex(m.pos, i, M, hw, hh);
+  const int4 *vb = vbuf + (size_t)b * m.V;
+  auto vertex = [&](int i) -> Vtx {          // the pre-pass' record: exactly xform_vertex's values
     const int4 q = vb[i];
     Vtx o;
     o.X = q.x;
@@ -205,9 +259,9 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     return o;
   };
 
-  // ---- pass 1: stream triangles, resolve visibility in LDS.  Four triangles per thread are in flight at a time: their index
-  // and vertex loads (two dependent memory round trips) are issued together - at 1 .. 64 hypotheses a workgroup is alone on
-  // its CU and the loop is latency-bound (tracking: 86 -> see DESIGN.md us per render); coverage and keys do not depend on order.
+  // ---- pass 1: walk the strip's face list, resolve visibility in LDS.  Four triangles per thread are in flight at a time:
+  // their list, index and vertex loads (three dependent memory round trips) are issued together; coverage and keys do not
+  // depend on the order.
   auto raster_tri = [&](const int t, const int *fi3, const Vtx &v0, const Vtx &v1, const Vtx &v2) __attribute__((always_inline)) {
     if (!(v0.ok && v1.ok && v2.ok)) {
       if (!(v0.w > 0.f || v1.w > 0.f || v2.w > 0.f)) return;      // entirely behind the camera
@@ -303,22 +357,24 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
       }
     }
   };
-  for (int t0 = threadIdx.x; t0 < m.F; t0 += 4 * RB_THREADS) {
-    int fi[4][3];
-    Vtx fv[4][3];
+  const int nlist = count[(size_t)b * n_strips + strip];
+  const int *mylist = list + ((size_t)b * n_strips + strip) * m.F;
+  for (int e0 = threadIdx.x; e0 < nlist; e0 += RB_FLY * RB_THREADS) {
+    int ft[RB_FLY], fi[RB_FLY][3];
+    Vtx fv[RB_FLY][3];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int t = min(t0 + u * RB_THREADS, m.F - 1);
+    for (int u = 0; u < RB_FLY; ++u) ft[u] = mylist[min(e0 + u * RB_THREADS, nlist - 1)];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) fi[u][k] = m.faces[t * 3 + k];
-    }
+    for (int u = 0; u < RB_FLY; ++u)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+      for (int k = 0; k < 3; ++k) fi[u][k] = m.faces[ft[u] * 3 + k];
+#pragma unroll
+    for (int u = 0; u < RB_FLY; ++u)
 #pragma unroll
       for (int k = 0; k < 3; ++k) fv[u][k] = vertex(fi[u][k]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (t0 + u * RB_THREADS < m.F) raster_tri(t0 + u * RB_THREADS, fi[u], fv[u][0], fv[u][1], fv[u][2]);
+    for (int u = 0; u < RB_FLY; ++u)
+      if (e0 + u * RB_THREADS < nlist) raster_tri(ft[u], fi[u], fv[u][0], fv[u][1], fv[u][2]);
   }
   __syncthreads();
 
@@ -493,37 +549,56 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   }
 }
 
+// Strips per hypothesis and the scratch a launch needs: transformed vertices (16 B each), list counters, face lists (worst
+// case: every face in every strip).
+RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu) {
+  RenderPlan p;
+  const size_t max_lds = 150 * 1024;
+  int rows_max = (int)(max_lds / ((size_t)Wo * 8));
+  if (rows_max > Ho) rows_max = Ho;
+  if (rows_max < 1) rows_max = 1;
+  int S = (Ho + rows_max - 1) / rows_max;
+  // 40-row strips of a 160-row crop (50 KB: three workgroups per CU); thinner ones while the launch is still under two
+  // workgroups per CU - a workgroup's resolve pass shrinks with its strip, and the face lists keep the triangle pass from
+  // being repeated per strip (a pixel's result does not depend on the strip it is in)
+  while (S < 4 && Ho / (S * 2) >= 8) S *= 2;
+  while ((size_t)N * S < (size_t)2 * num_cu && S < 16 && Ho / (S * 2) >= 8) S *= 2;
+  p.S = S;
+  p.strip_rows = (Ho + S - 1) / S;
+  p.S = (Ho + p.strip_rows - 1) / p.strip_rows;
+  p.vbuf_bytes = ((size_t)N * V * 16 + 255) & ~(size_t)255;
+  p.count_bytes = ((size_t)N * p.S * 4 + 255) & ~(size_t)255;
+  p.list_bytes = (size_t)N * p.S * F * 4;
+  p.total = p.vbuf_bytes + p.count_bytes + p.list_bytes;
+  return p;
+}
+
 int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s) {
   FP_REQUIRE(a.N >= 0 && a.Ho > 0 && a.Wo > 0, "render: bad shape N=%d out=%dx%d", a.N, a.Ho, a.Wo);
   if (a.N == 0) return FP_OK;
-  const size_t max_lds = 150 * 1024;
-  int strip_rows = (int)(max_lds / ((size_t)a.Wo * 8));
-  FP_REQUIRE(strip_rows >= 1, "render: output width %d too large for one LDS strip", a.Wo);
-  if (strip_rows > a.Ho) strip_rows = a.Ho;
-  int n_strips = (a.Ho + strip_rows - 1) / strip_rows;
-  // a handful of hypotheses (tracking): more, thinner strips - the per-pixel resolve pass of a workgroup shrinks with its strip
-  // and the launch still fits one round of workgroups (a pixel's result does not depend on the strip it is in)
-  while (a.N * n_strips * 2 <= ctx->num_cu / 2 && n_strips < 8 && a.Ho / (n_strips * 2) >= 8) n_strips *= 2;
-  strip_rows = (a.Ho + n_strips - 1) / n_strips;  // balance
-  size_t lds = (size_t)strip_rows * a.Wo * 8;
-  dim3 grid((unsigned)(a.N * n_strips));
+  FP_REQUIRE((size_t)a.Wo * 8 <= 150 * 1024, "render: output width %d too large for one LDS strip", a.Wo);
+  const RenderPlan pl = render_plan(a.N, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
+  FP_REQUIRE(a.scratch && a.scratch_bytes >= pl.total, "render: scratch of %zu bytes needed, %zu given", pl.total, a.scratch_bytes);
+  int4 *vbuf = (int4 *)a.scratch;
+  int *count = (int *)((char *)a.scratch + pl.vbuf_bytes);
+  int *list = (int *)((char *)a.scratch + pl.vbuf_bytes + pl.count_bytes);
+  const size_t lds = (size_t)pl.strip_rows * a.Wo * 8;
   ProfScope ps(ctx, s, "render", 0);
-  const int4 *vbuf = (const int4 *)a.vbuf;
-  if (vbuf) {
-    hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, (int4 *)a.vbuf);
-    FP_CHECK_HIP(hipGetLastError());
-  }
+  hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, vbuf, count, pl.S);
+  hipLaunchKernelGGL(bin_faces_kernel, dim3((a.mesh.F + 255) / 256, a.N), dim3(256), 0, s, a, (const int4 *)vbuf, count, list, pl.S, pl.strip_rows);
+  FP_CHECK_HIP(hipGetLastError());
   auto go = [&](auto kern, bool *attr_set) -> int {
     if (!*attr_set) {              // once per instantiation, for the largest strip: not a stream operation
-      FP_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+      FP_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       *attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(RB_THREADS), lds, s, a, strip_rows, n_strips, vbuf);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * pl.S)), dim3(RB_THREADS), lds, s, a, pl.strip_rows, pl.S, (const int4 *)vbuf, (const int *)count,
+                       (const int *)list);
     return FP_OK;
   };
-  static bool set11 = false, set10 = false, set01 = false, set00 = false;
-  if (a.net_out) FP_TRY(vbuf ? go(render_kernel<1, true>, &set11) : go(render_kernel<1, false>, &set10));
-  else FP_TRY(vbuf ? go(render_kernel<0, true>, &set01) : go(render_kernel<0, false>, &set00));
+  static bool set1 = false, set0 = false;
+  if (a.net_out) FP_TRY(go(render_kernel<1>, &set1));
+  else FP_TRY(go(render_kernel<0>, &set0));
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

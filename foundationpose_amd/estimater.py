@@ -91,6 +91,10 @@ class FoundationPose:
       if torch.is_tensor(value):
         setattr(self, name, value.to(s))
     self.mesh_tensors = {k: v.to(s) for k, v in self.mesh_tensors.items()}
+    if self.refiner is not None:        # src/estimater.py:97-100: the two networks move as well
+      self.refiner.to_device(s)
+    if self.scorer is not None:
+      self.scorer.to_device(s)
     if self.glctx is not None:
       self.glctx = U.RasterizeContext(s)
 

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import FP_NET_REFINE, FpRefineCfg, byref, check, k_ptr, lib, ptr, stream_ptr
 from .Utils import _ctx_of, make_mesh_tensors
-from .config import Cfg, load_run_dir
+from .config import Cfg, check_network_cfg, load_run_dir
 from .pose_dataset import BatchPoseData, planar_views
 
 
@@ -94,10 +94,7 @@ class PoseRefinePredictor:
     for k in ('input_resize', 'trans_normalizer', 'rot_normalizer'):
       if k not in self.cfg:
         raise KeyError(f"refiner config has no '{k}' (the reference reads it without a default)")
-    if tuple(self.cfg['input_resize']) != (160, 160):
-      raise NotImplementedError('the HIP networks are specialised for input_resize=(160,160)')
-    if self.cfg['use_normal']:
-      raise NotImplementedError('use_normal=True is not implemented (no released model uses it)')
+    check_network_cfg(self.cfg, state_dict, 'encodeA.0.net.0.weight', 'predict_pose_refine.py')
     self.device = torch.device(device)
     self.ctx = _lib.Context.get(self.device)
     self.model = _lib.DeviceNet(self.ctx, FP_NET_REFINE, state_dict, use_bn=bool(self.cfg['use_BN']))
@@ -108,6 +105,14 @@ class PoseRefinePredictor:
     logging.info("init done")
     self.last_trans_update = None
     self.last_rot_update = None
+
+  def to_device(self, device):
+    """Move the network to `device` (src/estimater.py:97-100 does `self.refiner.model.to(s)`): the context and the packed weights
+    follow; later predict() calls run there."""
+    self.device = torch.device(device)
+    self.ctx = _lib.Context.get(self.device)
+    self.model.to(self.device)
+    return self
 
   def _c_cfg(self):
     """fp_refine_cfg for the C-ABI from the reference's config keys (predict_pose_refine.py:195-231)."""

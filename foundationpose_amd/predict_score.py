@@ -7,7 +7,7 @@ import torch
 from . import _lib
 from ._lib import FP_NET_SCORE, check, k_ptr, lib, ptr, stream_ptr
 from .Utils import _ctx_of, make_mesh_tensors
-from .config import Cfg, load_run_dir
+from .config import Cfg, check_network_cfg, load_run_dir
 from .pose_dataset import BatchPoseData, planar_views
 from .predict_pose_refine import crop_net_input
 
@@ -70,15 +70,20 @@ class ScorePredictor:
       self.cfg['crop_ratio'] = 1.2
     if 'input_resize' not in self.cfg:
       raise KeyError("scorer config has no 'input_resize'")
-    if tuple(self.cfg['input_resize']) != (160, 160):
-      raise NotImplementedError('the HIP networks are specialised for input_resize=(160,160)')
-    if self.cfg['use_normal']:
-      raise NotImplementedError('use_normal=True is not implemented (no released model uses it)')
+    check_network_cfg(self.cfg, state_dict, 'encoderA.0.net.0.weight', 'predict_score.py')
     self.device = torch.device(device)
     self.ctx = _lib.Context.get(self.device)
     self.model = _lib.DeviceNet(self.ctx, FP_NET_SCORE, state_dict, use_bn=bool(self.cfg['use_BN']))
     self.dataset = None
     logging.info("init done")
+
+  def to_device(self, device):
+    """Move the network to `device` (src/estimater.py:97-100 does `self.scorer.model.to(s)`): the context and the packed weights
+    follow; later predict() calls run there."""
+    self.device = torch.device(device)
+    self.ctx = _lib.Context.get(self.device)
+    self.model.to(self.device)
+    return self
 
   @torch.inference_mode()
   def extract_features(self, rgb, depth, K, ob_in_cams, mesh=None, mesh_tensors=None, glctx=None, mesh_diameter=None):

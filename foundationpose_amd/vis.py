@@ -18,27 +18,22 @@ def _jet(v_u8):
 
 
 def depth_to_vis(depth, zmin=None, zmax=None, mode='rgb', inverse=True):
-  """src/Utils.py:456-478."""
-  depth = np.asarray(depth, dtype=np.float32)
-  if zmin is None:
-    zmin = depth.min()
-  if zmax is None:
-    zmax = depth.max()
-  if inverse:
-    invalid = depth < 0.001
-    vis = zmin / (depth + 1e-8)
-    vis[invalid] = 0
-  else:
-    depth = depth.clip(zmin, zmax)
-    invalid = (depth == zmin) | (depth == zmax)
-    with np.errstate(divide='ignore', invalid='ignore'):
-      vis = (depth - zmin) / (zmax - zmin)
-    vis[invalid] = 1
-  if mode == 'gray':
-    return (vis * 255).clip(0, 255).astype(np.uint8)
-  if mode == 'rgb':
-    return _jet((np.nan_to_num(vis) * 255).astype(np.uint8))
-  raise RuntimeError
+  """Depth image -> uint8 picture, the rule of src/Utils.py:456-478: `inverse` shows zmin / depth (invalid pixels, depth < 1 mm,
+  black); otherwise the depth is normalised to [zmin, zmax] and every pixel at or beyond either bound is drawn at full scale.
+  zmin / zmax default to the image's own extremes.  mode 'gray' -> (H,W), 'rgb' -> JET-coloured (H,W,3)."""
+  if mode not in ('gray', 'rgb'):
+    raise RuntimeError(f"depth_to_vis: mode {mode!r} (the reference knows 'gray' and 'rgb')")
+  d = np.asarray(depth, dtype=np.float32)
+  lo = d.min() if zmin is None else zmin
+  hi = d.max() if zmax is None else zmax
+  with np.errstate(divide='ignore', invalid='ignore'):
+    if inverse:
+      level = np.where(d < 0.001, 0.0, lo / (d + 1e-8))
+    else:
+      inside = (d > lo) & (d < hi)
+      level = np.where(inside, (d - lo) / (hi - lo), 1.0)
+  gray = np.clip(np.nan_to_num(level) * 255, 0, 255).astype(np.uint8)
+  return gray if mode == 'gray' else _jet(gray)
 
 
 def make_grid_image(imgs, nrow, padding=5, pad_value=255):

@@ -113,3 +113,23 @@ def test_predictors_built_from_run_dirs_match_injected_ones(tmp_path, monkeypatc
   monkeypatch.setenv('FOUNDATIONPOSE_WEIGHTS', root)
   with pytest.raises(KeyError, match='rot_normalizer'):
     PoseRefinePredictor()
+
+
+def test_unsupported_network_configs_are_refused_with_the_reference_line():
+  """configurations outside what the HIP networks implement are refused at construction - before any device
+  call, so this runs on the CPU - with a message that names the reference lines whose behaviour would be needed."""
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+  from foundationpose_amd.predict_score import ScorePredictor
+  rsd, ssd = {'encodeA.0.net.0.weight': torch.zeros(64, 6, 7, 7)}, {'encoderA.0.net.0.weight': torch.zeros(64, 6, 7, 7)}
+  for P, sd, base, ref in ((PoseRefinePredictor, rsd, C.REFINE_DEFAULT, 'predict_pose_refine.py'), (ScorePredictor, ssd, C.SCORE_DEFAULT, 'predict_score.py')):
+    with pytest.raises(NotImplementedError, match=ref + ':64-71'):
+      P(state_dict=sd, cfg=dict(base, input_resize=[128, 128]))
+    with pytest.raises(NotImplementedError, match='src/Utils.py:191-199'):
+      P(state_dict=sd, cfg=dict(base, use_normal=True))
+    cfg4 = dict(base)
+    cfg4.pop('c_in')                     # the reference's back-compat default c_in=4 meets a 6-channel checkpoint: load_state_dict raises there
+    with pytest.raises(ValueError, match='c_in=4'):
+      P(state_dict=sd, cfg=cfg4)
+    sd4 = {k: torch.zeros(64, 4, 7, 7) for k in sd}
+    with pytest.raises(ValueError, match='feeds 6 channels'):
+      P(state_dict=sd4, cfg=dict(base, c_in=4))

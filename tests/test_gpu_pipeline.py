@@ -414,3 +414,35 @@ def test_register_textured_symmetric_object():
   assert int(est.best_id) == int(orc.best_id)
   np.testing.assert_allclose(pose_g, pose_o, atol=1e-3)
   assert util.nearest_pose_error(est.poses.cpu().numpy(), np.asarray(orc.poses)) < 1e-3
+
+
+def test_to_device_moves_the_predictors(nets_gpu):
+  """src/estimater.py:88-102: to_device moves the tensors, both networks and re-creates the raster context.  On a one-GPU box
+  the target is the device everything already lives on (no copy is made); the rebuild that a move to another GPU performs -
+  fp_net re-created from the host copies of the parameters, the old one freed - is driven directly and must not change a bit."""
+  from foundationpose_amd import _lib
+  ng = nets_gpu
+  A, B = net_inputs(5, 3)
+  before = _refine_gpu(ng, ng['rnet'], A, B)
+  net = _lib.DeviceNet(ng['ctx'], _lib.FP_NET_REFINE, ng['rsd'], True)
+  old = net.handle
+  assert net.to('cuda:0') is net and net.handle is old              # same device: nothing happens
+  net._create(ng['ctx'])                                            # what to() does for a different device
+  _lib.lib().fp_net_destroy(old)
+  after = _refine_gpu(ng, net, A, B)
+  assert torch.equal(before[0], after[0]) and torch.equal(before[1], after[1])
+
+  class Pred:                                                       # records what FoundationPose.to_device asks of a predictor
+    def __init__(self):
+      self.moved = None
+
+    def to_device(self, s):
+      self.moved = s
+  from foundationpose_amd.estimater import FoundationPose
+  est = FoundationPose.__new__(FoundationPose)
+  est.mesh_tensors = {'pos': torch.zeros(3, 3)}
+  est.some_tensor = torch.ones(2)
+  est.refiner, est.scorer, est.glctx = Pred(), Pred(), None
+  est.to_device('cuda:0')
+  assert est.refiner.moved == 'cuda:0' and est.scorer.moved == 'cuda:0'
+  assert est.some_tensor.is_cuda and est.mesh_tensors['pos'].is_cuda
