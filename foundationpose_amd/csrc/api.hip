@@ -196,6 +196,11 @@ extern "C" int fp_mesh_create(fp_ctx *ctx, const float *h_pos, int V, const int3
   auto run = [&]() -> int {
     FP_TRY(up(m, h_pos, (size_t)V * 3, &m->d.pos));
     FP_TRY(up(m, h_faces, (size_t)F * 3, &m->d.faces));
+    {
+      std::vector<int4> f4(F);
+      for (int t = 0; t < F; ++t) f4[t] = make_int4(h_faces[t * 3], h_faces[t * 3 + 1], h_faces[t * 3 + 2], 0);
+      FP_TRY(up(m, f4.data(), (size_t)F, &m->d.faces4));
+    }
     FP_TRY(up(m, h_vnormals, (size_t)V * 3, &m->d.vnormals));
     if (textured) {
       FP_TRY(up(m, h_uv, (size_t)n_uv * 2, &m->d.uv));

@@ -45,6 +45,7 @@ struct MeshDev {
   const float *pos, *vnormals, *vcolor, *uv, *tex;
   const int32_t *faces, *uv_idx;
   int V, F, texH, texW;
+  const int4 *faces4;                   // the face indices as 16-byte records {i0, i1, i2, 0}: one load per face in the rasteriser
 };
 
 struct fp_mesh {
@@ -265,8 +266,9 @@ struct RenderArgs {
   f16 *net_out;                         // mode 1
   float mesh_diameter, invalid_thres;
   int normalize_xyz;
-  void *scratch = nullptr;              // render_plan(...).total bytes: transformed vertices, per-strip face lists (required)
+  void *scratch = nullptr;              // render_plan(...).total bytes: the per-(hypothesis, vertex) records of the pre-pass (required)
   size_t scratch_bytes = 0;
+  int dbg = 0;                          // FP_RENDER_DBG (timing experiments: phases switched off)
   // non-default lighting / projection of nvdiffrast_render (src/Utils.py:159-162,200-211)
   int light_mode = 0;                   // 0: light_dir = (0,0,1), the default; 1: direction light_vec = -light_dir; 2: point light at light_vec (light_dir=None)
   float light_vec[3] = {0.f, 0.f, -1.f};
@@ -276,8 +278,8 @@ struct RenderArgs {
   double proj[16] = {0};
 };
 struct RenderPlan {
-  int S, strip_rows;                    // strips per hypothesis, rows per strip
-  size_t vbuf_bytes, count_bytes, list_bytes, total;
+  int S, strip_rows, lds_verts;         // strips per hypothesis, rows per strip, whether the triangle pass keeps the vertex records in LDS
+  size_t lds_bytes, a_lds, c_bytes, b_bytes, a_bytes, count_bytes, list_bytes, total;
 };
 RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu);
 int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s);

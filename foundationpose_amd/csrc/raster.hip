@@ -1,20 +1,27 @@
 // Batched pose-hypothesis rasteriser for gfx950 (replaces nvdiffrast in src/Utils.py:133-219) and the
 // crop-window transform (src/Utils.py:577-621).
 //
-// Regime: a 160x160 crop of a ~16k-face mesh => triangles are 1-3 pixels ("micro-polygons"), and about half of them cover
-// no pixel centre at all.  Three launches per batch of hypotheses:
-//   1. xform_vertices_kernel: every (hypothesis, vertex) transformed ONCE (clip matrix in float64, 1/16-px snapping) -> 16 B;
-//   2. bin_faces_kernel: one thread per (hypothesis, face) computes the face's pixel range with the rasteriser's own integer
-//      arithmetic, drops faces that cover no pixel centre of the crop (and zero-area ones), and appends the face id to the
-//      list of every horizontal STRIP of the crop its rows touch (wave-aggregated atomic append; the order inside a list is
-//      not deterministic and does not matter: visibility below is a minimum over (depth, face id) keys);
-//   3. render_kernel: one workgroup = one hypothesis x one strip (40 rows x 160 px x 8 B = 50 KiB of LDS at >= 64 hypotheses,
-//      thinner strips for fewer; several workgroups per CU).  The strip's FRAMEBUFFER lives in LDS; the lanes walk the strip's
-//      face list (whole triangles per lane: 64-bit / 32-bit integer edge functions, top-left rule) and resolve visibility with
-//      one ds_min_u64 per covered pixel on the packed key (ordered z/w : 32 | face id : 32) - nearest wins, ties go to the
-//      lower face id, independent of lane scheduling and list order => bit-reproducible.
-//      (Until round 3 a workgroup walked ALL faces of the mesh for each of its two 80-row strips: 200 us per 252-hypothesis
-//      launch, 65 us of a workgroup's 110 in the triangle loop.)
+// Regime: a 160x160 crop of a ~16k-face mesh => triangles are 1-3 pixels ("micro-polygons"), about half of them cover no pixel
+// centre at all, and a few (silhouette slivers, cap fans) span dozens.  What the rasteriser of rounds 1-2 spent its time on was not
+// memory but LANE UTILISATION: every strip workgroup walked all faces, so its divergent per-triangle pixel loop ran for the few lanes
+// of a wave whose face touched the strip, as long as the largest triangle among them needed (measured by switching the phases off one
+// by one).  Three launches per batch of hypotheses now:
+//   1. xform_vertices_kernel: every (hypothesis, vertex) ONCE -> three records: A (8 B) the snapped window position as two
+//      int16 + z/w, for the triangle pass; B (32 B) camera-space position, Lambert term, vertex colour and w, everything the
+//      shading interpolates; C (16 B) the full-precision position for the rare triangles A cannot describe;
+//   2. classify_faces_kernel: one workgroup per hypothesis keeps its A records in LDS, walks the faces ONCE and appends each
+//      face that can cover a pixel centre to the list of every horizontal STRIP of the crop it touches, by the number of candidate
+//      pixels it has there: small (<= 4) and medium (<= 32) in one list from either end, large ones and those the 32-bit edge
+//      functions cannot take (a vertex beyond +-1024 px, or on / behind the camera plane) in another.  The counters are in LDS;
+//      the order inside a list is not deterministic and does not matter (visibility below is a minimum over keys);
+//   3. render_kernel: one workgroup (16 waves) = one hypothesis x one strip (40 rows x 160 px x 8 B = 50 KiB at >= 64 hypotheses,
+//      thinner strips for fewer).  The strip's FRAMEBUFFER and the hypothesis' A records (64 KiB for 8k vertices) live in LDS.  A
+//      lane takes one small or medium triangle from the dense list (neighbours in a wave have similar pixel counts), reads its
+//      vertices from LDS and rasterises it (32-bit integer edge functions, top-left rule), resolving visibility with one
+//      ds_min_u64 per covered pixel on the packed key (ordered z/w : 32 | face id : 32) - nearest wins, ties go to the lower
+//      face id, independent of lane scheduling and list order => bit-reproducible.  The second list is worked off one triangle
+//      per WAVE, one candidate pixel per lane (64-bit edge functions / homogeneous form).  The covered pixels of the strip are
+//      then compacted into a queue and resolved one per lane.
 //   A second pass resolves each pixel: perspective-correct barycentrics, attribute interpolation,
 //   shading, and either fp32 channels-last maps (API parity with nvdiffrast_render) or the fused
 //   network-ready fp16 NHWC8 tensor (rgb, (xyz-t)*2/diam with invalid masking; h5_dataset.py:92-99),
@@ -22,14 +29,9 @@
 // Triangles that straddle the camera plane are rasterised in homogeneous coordinates (below).
 // The arithmetic is mirrored 1:1 by oracle/raster_c.c.
 #include "common.h"
+#include <cstdlib>
 
-#define RB_THREADS 512
-#ifndef RB_MINW
-#define RB_MINW 4     // waves per SIMD the register budget is held to: two 8-wave workgroups per CU
-#endif
-#ifndef RB_FLY
-#define RB_FLY 2      // triangles in flight per thread in the list walk (4 need 159 VGPRs: one workgroup per CU instead of two)
-#endif
+#define RB_THREADS 1024
 
 __device__ __forceinline__ unsigned ordered_key(float z) {
   unsigned b = __float_as_uint(z);
@@ -163,93 +165,154 @@ __device__ void clip_matrix(const RenderArgs &a, int b, const float *pose, float
   for (int i = 0; i < 16; ++i) sM[i] = (float)Mx[i];
 }
 
-// Vertex pre-pass for the fused network path: every hypothesis' vertices transformed ONCE (the triangle loop of render_kernel
-// otherwise re-transforms a vertex for each of its ~6 triangles, in each strip, behind two dependent global round trips).
-// One int4 per vertex: X (INT_MIN = behind the camera / off range), Y, bits of z/w, bits of w - exactly xform_vertex's values.
-__global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 *__restrict__ vout, int *__restrict__ count, int S) {
+// Vertex pre-pass: every hypothesis' vertices ONCE.
+//   C (int4):   X (INT_MIN = behind the camera / off range), Y, bits of z/w, bits of w - exactly xform_vertex's values;
+//   A (uint2):  X | Y << 16 as int16 where |X|, |Y| < 16384 (the range of the 32-bit edge functions), else RB_A_NONE; bits of z/w;
+//   B (2 x float4): camera-space position (pts_cam, src/Utils.py:168) and the vertex' Lambert term (src/Utils.py:200-206) - the
+//               expressions the per-pixel resolve evaluated until round 3, moved here verbatim -, then colour and w.
+#define RB_A_NONE 0x7fff7fffu
+__global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 *__restrict__ recC, float4 *__restrict__ recB, uint2 *__restrict__ recA) {
   __shared__ float sM[16];
+  __shared__ float sP[12];
   const int b = blockIdx.y;
-  if (threadIdx.x == 0) clip_matrix(a, b, a.poses + (size_t)b * 16, sM);
-  if (blockIdx.x == 0)                  // the strip lists of this hypothesis start empty (bin_faces_kernel runs behind this launch)
-    for (int q = threadIdx.x; q < S; q += 256) count[(size_t)b * S + q] = 0;
+  if (threadIdx.x == 0) {
+    clip_matrix(a, b, a.poses + (size_t)b * 16, sM);
+    for (int i = 0; i < 12; ++i) sP[i] = a.poses[(size_t)b * 16 + i];
+  }
   __syncthreads();
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= a.mesh.V) return;
   float M[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) M[i] = sM[i];
-  const Vtx o = xform_vertex(a.mesh.pos, v, M, 0.5f * (float)a.Wo, 0.5f * (float)a.Ho);
-  vout[(size_t)b * a.mesh.V + v] = make_int4(o.ok ? o.X : (int)0x80000000, o.Y, __float_as_int(o.zn), __float_as_int(o.w));
+  const MeshDev &m = a.mesh;
+  const Vtx o = xform_vertex(m.pos, v, M, 0.5f * (float)a.Wo, 0.5f * (float)a.Ho);
+  const float P0 = sP[0], P1 = sP[1], P2 = sP[2], P3 = sP[3], P4 = sP[4], P5 = sP[5], P6 = sP[6], P7 = sP[7], P8 = sP[8],
+              P9 = sP[9], P10 = sP[10], P11 = sP[11];
+  const float px = m.pos[v * 3], py = m.pos[v * 3 + 1], pz = m.pos[v * 3 + 2];
+  float pc[3], nc[3];
+  pc[0] = fmaf(P0, px, fmaf(P1, py, fmaf(P2, pz, P3)));
+  pc[1] = fmaf(P4, px, fmaf(P5, py, fmaf(P6, pz, P7)));
+  pc[2] = fmaf(P8, px, fmaf(P9, py, fmaf(P10, pz, P11)));
+  const float nx = m.vnormals[v * 3], ny = m.vnormals[v * 3 + 1], nz = m.vnormals[v * 3 + 2];
+  nc[0] = fmaf(P0, nx, fmaf(P1, ny, P2 * nz));
+  nc[1] = fmaf(P4, nx, fmaf(P5, ny, P6 * nz));
+  nc[2] = fmaf(P8, nx, fmaf(P9, ny, P10 * nz));
+  float nn = sqrtf(fmaf(nc[0], nc[0], fmaf(nc[1], nc[1], nc[2] * nc[2])));
+  nn = nn > 1e-12f ? nn : 1e-12f;
+  float dv;
+  if (a.light_mode == 0) {
+    dv = fminf(fmaxf(-(nc[2] / nn), 0.f), 1.f);
+  } else {                        // src/Utils.py:200-205: normalize(vnormals_cam) . normalize(-light_dir | light_pos - pts_cam), clipped to [0,1]
+    float L[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) L[c] = a.light_mode == 1 ? a.light_vec[c] : a.light_vec[c] - pc[c];
+    float ln = sqrtf(fmaf(L[0], L[0], fmaf(L[1], L[1], L[2] * L[2])));
+    ln = ln > 1e-12f ? ln : 1e-12f;
+    const float dt = fmaf(nc[0] / nn, L[0] / ln, fmaf(nc[1] / nn, L[1] / ln, (nc[2] / nn) * (L[2] / ln)));
+    dv = fminf(fmaxf(dt, 0.f), 1.f);
+  }
+  const size_t r = (size_t)b * m.V + v;
+  recC[r] = make_int4(o.ok ? o.X : (int)0x80000000, o.Y, __float_as_int(o.zn), __float_as_int(o.w));
+  const bool small = o.ok && abs(o.X) < 16384 && abs(o.Y) < 16384;
+  recA[r] = make_uint2(small ? ((unsigned)o.X & 0xffffu) | ((unsigned)o.Y << 16) : RB_A_NONE, __float_as_uint(o.zn));
+  recB[2 * r] = make_float4(pc[0], pc[1], pc[2], dv);
+  float4 cw = make_float4(0.f, 0.f, 0.f, o.w);
+  if (m.vcolor) cw.x = m.vcolor[v * 3], cw.y = m.vcolor[v * 3 + 1], cw.z = m.vcolor[v * 3 + 2];
+  recB[2 * r + 1] = cw;
 }
 
+#define RB_SMALL 4                      // candidate pixels of a "small" triangle
+#define RB_MEDIUM 32                    // ... of a "medium" one; larger triangles are rasterised by a whole wave
+#define RB_SLOW 0x80000000u             // list B entry flag: needs the C records (64-bit edge functions or the homogeneous form)
+#define RB_MAXS 255                     // strips per hypothesis
 
-// Face lists per (hypothesis, strip).  A face is dropped here exactly when raster_tri() below would return without touching a
-// pixel for EVERY strip (pixel range empty after clamping to the crop, or zero area) - the same integers, so the images are
-// bit-identical to the unbinned walk; a face that straddles the camera plane cannot be bounded cheaply and goes to every strip.
-__global__ __launch_bounds__(256) void bin_faces_kernel(RenderArgs a, const int4 *__restrict__ vbuf, int *__restrict__ count,
-                                                        int *__restrict__ list, int S, int strip_rows) {
-  const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+// Per (hypothesis, strip) face lists.  A face is dropped here exactly when it cannot touch a pixel of the crop (pixel range empty
+// after clamping to the crop, or zero area): the same integers as in the triangle pass, so the images are bit-identical to a walk
+// over all faces.  count[(b*S + s)*4 + {0,1,2}] = small, medium, list-B entries; listA[(b*S + s)*F ..]: small from the front,
+// medium from the back; listB: large 32-bit triangles and RB_SLOW ones.
+__global__ __launch_bounds__(RB_THREADS) void classify_faces_kernel(RenderArgs a, const uint2 *__restrict__ recA, int *__restrict__ count,
+                                                                   unsigned *__restrict__ listA, unsigned *__restrict__ listB, int S, int strip_rows,
+                                                                   int lds_verts) {
+  extern __shared__ __attribute__((aligned(16))) uint2 cl_ldsA[];
+  __shared__ int cs[RB_MAXS + 1][3];
+  const int b = blockIdx.x;
   const MeshDev &m = a.mesh;
-  int s0 = 1, s1 = 0;                                   // strips [s0, s1] (empty)
-  if (t < m.F) {
-    const int4 *vb = vbuf + (size_t)b * m.V;
-    const int4 q0 = vb[m.faces[t * 3]], q1 = vb[m.faces[t * 3 + 1]], q2 = vb[m.faces[t * 3 + 2]];
-    const bool ok0 = q0.x != (int)0x80000000, ok1 = q1.x != (int)0x80000000, ok2 = q2.x != (int)0x80000000;
-    if (!(ok0 && ok1 && ok2)) {
-      if (__int_as_float(q0.w) > 0.f || __int_as_float(q1.w) > 0.f || __int_as_float(q2.w) > 0.f) s0 = 0, s1 = S - 1;
-    } else {
-      const long long X0 = q0.x, Y0 = q0.y, X1 = q1.x, Y1 = q1.y, X2 = q2.x, Y2 = q2.y;
-      const long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
-      const int xmin = min(q0.x, min(q1.x, q2.x)), xmax = max(q0.x, max(q1.x, q2.x));
-      const int ymin = min(q0.y, min(q1.y, q2.y)), ymax = max(q0.y, max(q1.y, q2.y));
-      const int ia = max((xmin - 8 + 15) >> 4, 0), ib = min((xmax - 8) >> 4, a.Wo - 1);
-      const int ja = max((ymin - 8 + 15) >> 4, 0), jb = min((ymax - 8) >> 4, a.Ho - 1);
-      if (area != 0 && ia <= ib && ja <= jb) s0 = ja / strip_rows, s1 = jb / strip_rows;
+  const uint2 *gA = recA + (size_t)b * m.V;
+  for (int i = threadIdx.x; i < S * 3; i += RB_THREADS) cs[i / 3][i % 3] = 0;
+  if (lds_verts)
+    for (int i = threadIdx.x; i < m.V; i += RB_THREADS) cl_ldsA[i] = gA[i];
+  __syncthreads();
+  auto getA = [&](int i) -> uint2 { return lds_verts ? cl_ldsA[i] : gA[i]; };
+  unsigned *lA = listA + (size_t)b * S * m.F, *lB = listB + (size_t)b * S * m.F;
+  int4 f_n = make_int4(0, 0, 0, 0);
+  if ((int)threadIdx.x < m.F) f_n = m.faces4[threadIdx.x];
+  for (int t = threadIdx.x; t < m.F; t += RB_THREADS) {
+    const int4 f = f_n;
+    if (t + RB_THREADS < m.F) f_n = m.faces4[t + RB_THREADS];
+    const uint2 a0 = getA(f.x), a1 = getA(f.y), a2 = getA(f.z);
+    if (a0.x == RB_A_NONE || a1.x == RB_A_NONE || a2.x == RB_A_NONE) {
+      // cannot be bounded here: every strip looks at it (faces entirely behind the camera are dropped there)
+      for (int sI = 0; sI < S; ++sI) lB[(size_t)sI * m.F + atomicAdd(&cs[sI][2], 1)] = (unsigned)t | RB_SLOW;
+      continue;
+    }
+    const int X0 = (short)(a0.x & 0xffffu), Y0 = (int)a0.x >> 16, X1 = (short)(a1.x & 0xffffu), Y1 = (int)a1.x >> 16,
+              X2 = (short)(a2.x & 0xffffu), Y2 = (int)a2.x >> 16;
+    if ((X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0) == 0) continue;
+    const int xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+    const int ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+    const int ia = max((xmin - 8 + 15) >> 4, 0), ib = min((xmax - 8) >> 4, a.Wo - 1);
+    const int ja = max((ymin - 8 + 15) >> 4, 0), jb = min((ymax - 8) >> 4, a.Ho - 1);
+    if (ia > ib || ja > jb) continue;
+    const int bw = ib - ia + 1;
+    for (int sI = ja / strip_rows; sI <= jb / strip_rows; ++sI) {
+      const int rows = min(jb, (sI + 1) * strip_rows - 1) - max(ja, sI * strip_rows) + 1;
+      const int nc = bw * rows;
+      if (nc <= RB_SMALL) lA[(size_t)sI * m.F + atomicAdd(&cs[sI][0], 1)] = (unsigned)t;
+      else if (nc <= RB_MEDIUM) lA[(size_t)sI * m.F + (m.F - 1 - atomicAdd(&cs[sI][1], 1))] = (unsigned)t;
+      else lB[(size_t)sI * m.F + atomicAdd(&cs[sI][2], 1)] = (unsigned)t;
     }
   }
-  if (S <= 16) {                                        // one atomic per wave and strip
-    for (int s = 0; s < S; ++s) {
-      const bool in = s >= s0 && s <= s1;
-      const unsigned long long mk = __builtin_amdgcn_ballot_w64(in);
-      if (mk == 0) continue;
-      int base = 0;
-      if (lane == __builtin_ctzll(mk)) base = atomicAdd(&count[(size_t)b * S + s], __builtin_popcountll(mk));
-      base = __shfl(base, __builtin_ctzll(mk));
-      if (in) list[((size_t)b * S + s) * m.F + base + __builtin_popcountll(mk & ((1ull << lane) - 1))] = t;
-    }
-  } else {
-    for (int s = s0; s <= s1; ++s) list[((size_t)b * S + s) * m.F + atomicAdd(&count[(size_t)b * S + s], 1)] = t;
-  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S * 3; i += RB_THREADS) count[((size_t)b * S + i / 3) * 4 + i % 3] = cs[i / 3][i % 3];
 }
 
 template <int MODE>
-__global__ __launch_bounds__(RB_THREADS, RB_MINW) void render_kernel(RenderArgs a, int strip_rows, int n_strips, const int4 *__restrict__ vbuf,
-                                                                 const int *__restrict__ count, const int *__restrict__ list) {
+__global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int strip_rows, int n_strips, const int4 *__restrict__ recC,
+                                                            const float4 *__restrict__ recB, const uint2 *__restrict__ recA, const int *__restrict__ count,
+                                                            const unsigned *__restrict__ listA, const unsigned *__restrict__ listB, int lds_verts) {
+  // dynamic LDS: the strip (8 B per pixel), the queue of its covered pixels (2 B per pixel), then (lds_verts) the hypothesis' A records
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];
   __shared__ float sM[16];
-  __shared__ float sP[12];
-  const int L = xcd_remap(blockIdx.x, gridDim.x);          // the strips of one hypothesis share an XCD's L2 (vertices, lists)
+  __shared__ int covn;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);          // the strips of one hypothesis share an XCD's L2
   const int b = L / n_strips, strip = L % n_strips;
   const int Ho = a.Ho, Wo = a.Wo;
   const int row0 = strip * strip_rows;  // GL (bottom-up) rows [row0, row1)
   const int row1 = min(Ho, row0 + strip_rows);
   const int npix = (row1 - row0) * Wo;
   const float *pose = a.poses + (size_t)b * 16;
+  const MeshDev &m = a.mesh;
+  const uint2 *gA = recA + (size_t)b * m.V;
+  unsigned short *covq = reinterpret_cast<unsigned short *>(zbuf + (size_t)strip_rows * Wo);
+  uint2 *ldsA = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(covq) + ((((size_t)strip_rows * Wo * 2) + 15) & ~(size_t)15));
 
   if (threadIdx.x == 0) {
     clip_matrix(a, b, pose, sM);
-    for (int i = 0; i < 12; ++i) sP[i] = pose[i];
+    covn = 0;
   }
   for (int i = threadIdx.x; i < npix; i += RB_THREADS) zbuf[i] = ~0ull;
+  if (lds_verts)
+    for (int i = threadIdx.x; i < m.V; i += RB_THREADS) ldsA[i] = gA[i];
   __syncthreads();
 
   // (the clip matrix stays in LDS: only triangles that straddle the camera plane read it)
   const float *M = sM;
   const float hw = 0.5f * (float)Wo, hh = 0.5f * (float)Ho;
-  const MeshDev &m = a.mesh;
-  const int4 *vb = vbuf + (size_t)b * m.V;
-  auto vertex = [&](int i) -> Vtx {          // the pre-pass' record: exactly xform_vertex's values
-    const int4 q = vb[i];
+  const int4 *vc = recC + (size_t)b * m.V;
+  const float4 *vbB = recB + 2 * (size_t)b * m.V;
+  auto getA = [&](int i) -> uint2 { return lds_verts ? ldsA[i] : gA[i]; };
+  auto unpack = [](const int4 &q) -> Vtx {      // record C: exactly xform_vertex's values
     Vtx o;
     o.X = q.x;
     o.Y = q.y;
@@ -258,37 +321,36 @@ __global__ __launch_bounds__(RB_THREADS, RB_MINW) void render_kernel(RenderArgs 
     o.ok = q.x != (int)0x80000000;
     return o;
   };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int *cnt = count + ((size_t)b * n_strips + strip) * 4;
+  const int n_small = (a.dbg & 4) ? 0 : cnt[0], n_med = (a.dbg & 4) ? 0 : cnt[1], n_b = (a.dbg & 20) ? 0 : cnt[2];
+  const unsigned *lA = listA + ((size_t)b * n_strips + strip) * m.F, *lB = listB + ((size_t)b * n_strips + strip) * m.F;
 
-  // ---- pass 1: walk the strip's face list, resolve visibility in LDS.  Four triangles per thread are in flight at a time:
-  // their list, index and vertex loads (three dependent memory round trips) are issued together; coverage and keys do not
-  // depend on the order.
-  auto raster_tri = [&](const int t, const int *fi3, const Vtx &v0, const Vtx &v1, const Vtx &v2) __attribute__((always_inline)) {
-    if (!(v0.ok && v1.ok && v2.ok)) {
-      if (!(v0.w > 0.f || v1.w > 0.f || v2.w > 0.f)) return;      // entirely behind the camera
-      float c[3][4];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) clip_coords(m.pos, fi3[k], M, c[k]);
-      const ClipTri T = clip_setup(c, hw, hh);
-      if (!T.valid) return;
-      for (int j = row0; j < row1; ++j)
-        for (int i = 0; i < Wo; ++i) {
-          float l[3], zp;
-          if (!clip_eval(T, i, j, l, &zp)) continue;
-          const unsigned long long key = ((unsigned long long)ordered_key(zp) << 32) | (unsigned)t;
-          atomicMin(&zbuf[(j - row0) * Wo + i], key);
-        }
-      return;
+  // ---- pass 1a, per lane: the small and medium triangles of this strip, 32-bit edge functions.  |X|,|Y| < 2^14 -> differences
+  // < 2^15, products < 2^30, sums < 2^31: the same integers as the 64-bit form below, so coverage, barycentrics and depth keys
+  // are bit-identical.  The list is dense and ordered small -> medium, so the lanes of a wave run similar pixel loops; the next
+  // entry's index quad is requested one iteration ahead.
+  {
+    const int n_a = n_small + n_med;
+    auto entry = [&](int e) -> int { return (int)(e < n_small ? lA[e] : lA[m.F - 1 - (e - n_small)]); };
+    int t_n = 0;
+    int4 f_n = make_int4(0, 0, 0, 0);
+    if ((int)threadIdx.x < n_a) {
+      t_n = entry(threadIdx.x);
+      f_n = m.faces4[t_n];
     }
-    // Triangles whose snapped coordinates stay within +-1024 px (all but the ones far outside the crop) take the same
-    // integer edge functions in 32-bit arithmetic: |X|,|Y| < 2^14 -> differences < 2^15, products < 2^30, sums < 2^31.
-    // The values are the same integers as in the 64-bit path, so coverage, barycentrics and depth keys are bit-identical.
-    const int amax = max(max(max(abs(v0.X), abs(v0.Y)), max(abs(v1.X), abs(v1.Y))), max(abs(v2.X), abs(v2.Y)));
-    if (amax < 16384) {
-      const int X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
+    for (int e = threadIdx.x; e < n_a; e += RB_THREADS) {
+      const int t = t_n;
+      const int4 f = f_n;
+      if (e + RB_THREADS < n_a) {
+        t_n = entry(e + RB_THREADS);
+        f_n = m.faces4[t_n];
+      }
+      if (a.dbg & 1) continue;
+      const uint2 a0 = getA(f.x), a1 = getA(f.y), a2 = getA(f.z);
+      const int X0 = (short)(a0.x & 0xffffu), Y0 = (int)a0.x >> 16, X1 = (short)(a1.x & 0xffffu), Y1 = (int)a1.x >> 16,
+                X2 = (short)(a2.x & 0xffffu), Y2 = (int)a2.x >> 16;
       int area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
-      if (area == 0) return;
-      const int sg = area > 0 ? 1 : -1;
-      area *= sg;
       const int xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
       const int ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
       int ia = (xmin - 8 + 15) >> 4, ib = (xmax - 8) >> 4, ja = (ymin - 8 + 15) >> 4, jb = (ymax - 8) >> 4;
@@ -296,7 +358,8 @@ __global__ __launch_bounds__(RB_THREADS, RB_MINW) void render_kernel(RenderArgs 
       ja = max(ja, row0);
       ib = min(ib, Wo - 1);
       jb = min(jb, row1 - 1);
-      if (ia > ib || ja > jb) return;
+      const int sg = area > 0 ? 1 : -1;
+      area *= sg;
       const int dx0 = sg * (X2 - X1), dy0 = sg * (Y2 - Y1);
       const int dx1 = sg * (X0 - X2), dy1 = sg * (Y0 - Y2);
       const int dx2 = sg * (X1 - X0), dy2 = sg * (Y1 - Y0);
@@ -304,6 +367,7 @@ __global__ __launch_bounds__(RB_THREADS, RB_MINW) void render_kernel(RenderArgs 
       const bool tl1 = (dy1 > 0) || (dy1 == 0 && dx1 < 0);
       const bool tl2 = (dy2 > 0) || (dy2 == 0 && dx2 < 0);
       const float fa = (float)area;
+      const float z0 = __uint_as_float(a0.y), z1 = __uint_as_float(a1.y), z2 = __uint_as_float(a2.y);
       for (int j = ja; j <= jb; ++j) {
         const int Py = 16 * j + 8;
         for (int i = ia; i <= ib; ++i) {
@@ -313,198 +377,104 @@ __global__ __launch_bounds__(RB_THREADS, RB_MINW) void render_kernel(RenderArgs 
           const int e2 = dx2 * (Py - Y0) - dy2 * (Px - X0);
           if (!((e0 > 0 || (e0 == 0 && tl0)) && (e1 > 0 || (e1 == 0 && tl1)) && (e2 > 0 || (e2 == 0 && tl2)))) continue;
           const float b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
-          const float zp = fmaf(b2, v2.zn, fmaf(b1, v1.zn, b0 * v0.zn));
+          const float zp = fmaf(b2, z2, fmaf(b1, z1, b0 * z0));
           if (!(zp >= -1.f && zp <= 1.f)) continue;
           const unsigned long long key = ((unsigned long long)ordered_key(zp) << 32) | (unsigned)t;
           atomicMin(&zbuf[(j - row0) * Wo + i], key);
         }
       }
-      return;
     }
-    long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
-    long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
-    if (area == 0) return;
-    long long sg = area > 0 ? 1 : -1;
-    area *= sg;
-    long long xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
-    long long ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
-    long long ia = (xmin - 8 + 15) >> 4, ib = (xmax - 8) >> 4, ja = (ymin - 8 + 15) >> 4, jb = (ymax - 8) >> 4;
-    ia = max(ia, 0ll);
-    ja = max(ja, (long long)row0);
-    ib = min(ib, (long long)Wo - 1);
-    jb = min(jb, (long long)row1 - 1);
-    if (ia > ib || ja > jb) return;
-    long long dx0 = sg * (X2 - X1), dy0 = sg * (Y2 - Y1);
-    long long dx1 = sg * (X0 - X2), dy1 = sg * (Y0 - Y2);
-    long long dx2 = sg * (X1 - X0), dy2 = sg * (Y1 - Y0);
-    bool tl0 = (dy0 > 0) || (dy0 == 0 && dx0 < 0);
-    bool tl1 = (dy1 > 0) || (dy1 == 0 && dx1 < 0);
-    bool tl2 = (dy2 > 0) || (dy2 == 0 && dx2 < 0);
-    float fa = (float)area;
-    for (long long j = ja; j <= jb; ++j) {
-      long long Py = 16 * j + 8;
-      for (long long i = ia; i <= ib; ++i) {
-        long long Px = 16 * i + 8;
-        long long e0 = dx0 * (Py - Y1) - dy0 * (Px - X1);
-        long long e1 = dx1 * (Py - Y2) - dy1 * (Px - X2);
-        long long e2 = dx2 * (Py - Y0) - dy2 * (Px - X0);
+  }
+  // ---- pass 1b, per wave: list B, one candidate pixel per lane.  A wave takes CHB entries at a time: lane l fetches entry l's
+  // index quad and its three C records (the triangles' loads in flight together), then the wave walks them with the records
+  // broadcast from the owning lane; everything but the pixel is wave-uniform.
+  constexpr int CHB = 4;        // entries a wave takes at a time (a strip has some tens of them: spread over all 16 waves)
+  for (int base = wave * CHB; base < n_b; base += (RB_THREADS / 64) * CHB) {
+    int my_t = 0;
+    int4 my_f = make_int4(0, 0, 0, 0), my_c0 = my_f, my_c1 = my_f, my_c2 = my_f;
+    if (lane < CHB && base + lane < n_b) {
+      my_t = (int)(lB[base + lane] & ~RB_SLOW);
+      my_f = m.faces4[my_t];
+      my_c0 = vc[my_f.x], my_c1 = vc[my_f.y], my_c2 = vc[my_f.z];
+    }
+    const int cntw = min(CHB, n_b - base);
+    for (int q = 0; q < cntw; ++q) {
+      auto bc4 = [&](const int4 &x) -> int4 {
+        return make_int4(__builtin_amdgcn_readlane(x.x, q), __builtin_amdgcn_readlane(x.y, q), __builtin_amdgcn_readlane(x.z, q),
+                         __builtin_amdgcn_readlane(x.w, q));
+      };
+      const int t = __builtin_amdgcn_readlane(my_t, q);
+      const int4 f = bc4(my_f);
+      const Vtx v0 = unpack(bc4(my_c0)), v1 = unpack(bc4(my_c1)), v2 = unpack(bc4(my_c2));
+      if (!(v0.ok && v1.ok && v2.ok)) {
+        // a vertex on or behind the camera plane (or projected out of range): homogeneous edge functions, every pixel of the strip
+        if (!(v0.w > 0.f || v1.w > 0.f || v2.w > 0.f)) continue;      // entirely behind the camera
+        float c[3][4];
+        const int fi3[3] = {f.x, f.y, f.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) clip_coords(m.pos, fi3[k], M, c[k]);
+        const ClipTri T = clip_setup(c, hw, hh);
+        if (!T.valid) continue;
+        for (int p = lane; p < npix; p += 64) {
+          const int jl = p / Wo, i = p - jl * Wo;
+          float l[3], zp;
+          if (!clip_eval(T, i, row0 + jl, l, &zp)) continue;
+          const unsigned long long key = ((unsigned long long)ordered_key(zp) << 32) | (unsigned)t;
+          atomicMin(&zbuf[p], key);
+        }
+        continue;
+      }
+      const long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
+      long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+      if (area == 0) continue;
+      const long long sg = area > 0 ? 1 : -1;
+      area *= sg;
+      const long long xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+      const long long ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+      long long ia = (xmin - 8 + 15) >> 4, ib = (xmax - 8) >> 4, ja = (ymin - 8 + 15) >> 4, jb = (ymax - 8) >> 4;
+      ia = max(ia, 0ll);
+      ja = max(ja, (long long)row0);
+      ib = min(ib, (long long)Wo - 1);
+      jb = min(jb, (long long)row1 - 1);
+      if (ia > ib || ja > jb) continue;
+      const long long dx0 = sg * (X2 - X1), dy0 = sg * (Y2 - Y1);
+      const long long dx1 = sg * (X0 - X2), dy1 = sg * (Y0 - Y2);
+      const long long dx2 = sg * (X1 - X0), dy2 = sg * (Y1 - Y0);
+      const bool tl0 = (dy0 > 0) || (dy0 == 0 && dx0 < 0);
+      const bool tl1 = (dy1 > 0) || (dy1 == 0 && dx1 < 0);
+      const bool tl2 = (dy2 > 0) || (dy2 == 0 && dx2 < 0);
+      const float fa = (float)area;
+      const int bw = (int)(ib - ia + 1), ncand = bw * (int)(jb - ja + 1);
+      for (int k = lane; k < ncand; k += 64) {
+        const int jj = k / bw;
+        const long long i = ia + (k - jj * bw), j = ja + jj;
+        const long long Px = 16 * i + 8, Py = 16 * j + 8;
+        const long long e0 = dx0 * (Py - Y1) - dy0 * (Px - X1);
+        const long long e1 = dx1 * (Py - Y2) - dy1 * (Px - X2);
+        const long long e2 = dx2 * (Py - Y0) - dy2 * (Px - X0);
         if (!((e0 > 0 || (e0 == 0 && tl0)) && (e1 > 0 || (e1 == 0 && tl1)) && (e2 > 0 || (e2 == 0 && tl2)))) continue;
-        float b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
-        float zp = fmaf(b2, v2.zn, fmaf(b1, v1.zn, b0 * v0.zn));
+        const float b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+        const float zp = fmaf(b2, v2.zn, fmaf(b1, v1.zn, b0 * v0.zn));
         if (!(zp >= -1.f && zp <= 1.f)) continue;
-        unsigned long long key = ((unsigned long long)ordered_key(zp) << 32) | (unsigned)t;
+        const unsigned long long key = ((unsigned long long)ordered_key(zp) << 32) | (unsigned)t;
         atomicMin(&zbuf[(int)(j - row0) * Wo + (int)i], key);
       }
     }
-  };
-  const int nlist = count[(size_t)b * n_strips + strip];
-  const int *mylist = list + ((size_t)b * n_strips + strip) * m.F;
-  for (int e0 = threadIdx.x; e0 < nlist; e0 += RB_FLY * RB_THREADS) {
-    int ft[RB_FLY], fi[RB_FLY][3];
-    Vtx fv[RB_FLY][3];
-#pragma unroll
-    for (int u = 0; u < RB_FLY; ++u) ft[u] = mylist[min(e0 + u * RB_THREADS, nlist - 1)];
-#pragma unroll
-    for (int u = 0; u < RB_FLY; ++u)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fi[u][k] = m.faces[ft[u] * 3 + k];
-#pragma unroll
-    for (int u = 0; u < RB_FLY; ++u)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fv[u][k] = vertex(fi[u][k]);
-#pragma unroll
-    for (int u = 0; u < RB_FLY; ++u)
-      if (e0 + u * RB_THREADS < nlist) raster_tri(ft[u], fi[u], fv[u][0], fv[u][1], fv[u][2]);
   }
   __syncthreads();
 
-  // ---- pass 2: per-pixel resolve + attribute interpolation + fused epilogue ----
-  const float P0 = sP[0], P1 = sP[1], P2 = sP[2], P3 = sP[3], P4 = sP[4], P5 = sP[5], P6 = sP[6], P7 = sP[7], P8 = sP[8],
-              P9 = sP[9], P10 = sP[10], P11 = sP[11];
-  for (int p = threadIdx.x; p < npix; p += RB_THREADS) {
+  // ---- pass 2: resolve.  (a) the covered pixels of the strip are queued (ballot + one LDS atomic per wave), the others written as
+  // zeros at once; (b) one covered pixel per lane: attribute interpolation, shading, fused epilogue.  Per pixel: the face's index quad,
+  // the three A records (LDS) and the three 32-byte B records - 7 scattered 16-byte loads on 4 cache lines (27 + 9 scattered 4-byte
+  // loads until round 3, with the position / normal transform and Lambert term of all three vertices recomputed per pixel).
+  float P0 = 0.f, P1 = 0.f, P2 = 0.f, P4 = 0.f, P5 = 0.f, P6 = 0.f, P8 = 0.f, P9 = 0.f, P10 = 0.f;
+  if (MODE == 0) {                      // the API form also interpolates the camera-space normals
+    P0 = pose[0], P1 = pose[1], P2 = pose[2], P4 = pose[4], P5 = pose[5], P6 = pose[6], P8 = pose[8], P9 = pose[9], P10 = pose[10];
+  }
+  auto emit = [&](int p, const float *col, const float *nrm, const float *p3) __attribute__((always_inline)) {
     const int jl = p / Wo, i = p - jl * Wo;
-    const int j = row0 + jl;
-    const int jo = Ho - 1 - j;  // flipped output row (src/Utils.py:216-218)
+    const int jo = Ho - 1 - (row0 + jl);  // flipped output row (src/Utils.py:216-218)
     const size_t o = ((size_t)b * Ho + jo) * Wo + i;
-    unsigned long long key = zbuf[p];
-    float col[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, p3[3] = {0, 0, 0};
-    if (key != ~0ull) {
-      int t = (int)(unsigned)(key & 0xffffffffull);
-      int i0 = m.faces[t * 3], i1 = m.faces[t * 3 + 1], i2 = m.faces[t * 3 + 2];
-      Vtx v0 = vertex(i0), v1 = vertex(i1), v2 = vertex(i2);
-      float fa, b0, b1, b2;
-      float u, v, w2;
-      const bool clipped = !(v0.ok && v1.ok && v2.ok);
-      const int amax = clipped ? 0 : max(max(max(abs(v0.X), abs(v0.Y)), max(abs(v1.X), abs(v1.Y))), max(abs(v2.X), abs(v2.Y)));
-      if (clipped) {                              // straddles the camera plane: weights from the homogeneous edge functions
-        float c[3][4];
-        const int id3[3] = {i0, i1, i2};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) clip_coords(m.pos, id3[k], M, c[k]);
-        const ClipTri T = clip_setup(c, hw, hh);
-        float l[3], zp;
-        (void)clip_eval(T, i, j, l, &zp);
-        const float ls = __fadd_rn(__fadd_rn(l[0], l[1]), l[2]);
-        u = __fdiv_rn(l[0], ls), v = __fdiv_rn(l[1], ls), w2 = (1.f - u) - v;
-        fa = b0 = b1 = b2 = 0.f;
-      } else if (amax < 16384) {                  // the same integers in 32-bit arithmetic (see pass 1)
-        const int X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
-        int area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
-        const int sg = area > 0 ? 1 : -1;
-        area *= sg;
-        const int Px = 16 * i + 8, Py = 16 * j + 8;
-        const int e0 = sg * ((X2 - X1) * (Py - Y1) - (Y2 - Y1) * (Px - X1));
-        const int e1 = sg * ((X0 - X2) * (Py - Y2) - (Y0 - Y2) * (Px - X2));
-        const int e2 = sg * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
-        fa = (float)area;
-        b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
-      } else {
-        long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
-        long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
-        long long sg = area > 0 ? 1 : -1;
-        area *= sg;
-        long long Px = 16ll * i + 8, Py = 16ll * j + 8;
-        long long e0 = sg * ((X2 - X1) * (Py - Y1) - (Y2 - Y1) * (Px - X1));
-        long long e1 = sg * ((X0 - X2) * (Py - Y2) - (Y0 - Y2) * (Px - X2));
-        long long e2 = sg * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
-        fa = (float)area;
-        b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
-      }
-      if (!clipped) {
-        float q0 = b0 / v0.w, q1 = b1 / v1.w, q2 = b2 / v2.w;
-        float qs = (q0 + q1) + q2;
-        u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
-      }
-      const int idx[3] = {i0, i1, i2};
-      float pc[3][3], nc[3][3], dv[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        float px = m.pos[idx[k] * 3], py = m.pos[idx[k] * 3 + 1], pz = m.pos[idx[k] * 3 + 2];
-        pc[k][0] = fmaf(P0, px, fmaf(P1, py, fmaf(P2, pz, P3)));
-        pc[k][1] = fmaf(P4, px, fmaf(P5, py, fmaf(P6, pz, P7)));
-        pc[k][2] = fmaf(P8, px, fmaf(P9, py, fmaf(P10, pz, P11)));
-        float nx = m.vnormals[idx[k] * 3], ny = m.vnormals[idx[k] * 3 + 1], nz = m.vnormals[idx[k] * 3 + 2];
-        nc[k][0] = fmaf(P0, nx, fmaf(P1, ny, P2 * nz));
-        nc[k][1] = fmaf(P4, nx, fmaf(P5, ny, P6 * nz));
-        nc[k][2] = fmaf(P8, nx, fmaf(P9, ny, P10 * nz));
-        float nn = sqrtf(fmaf(nc[k][0], nc[k][0], fmaf(nc[k][1], nc[k][1], nc[k][2] * nc[k][2])));
-        nn = nn > 1e-12f ? nn : 1e-12f;
-        if (a.light_mode == 0) {
-          dv[k] = fminf(fmaxf(-(nc[k][2] / nn), 0.f), 1.f);
-        } else {                        // src/Utils.py:200-205: normalize(vnormals_cam) . normalize(-light_dir | light_pos - pts_cam), clipped to [0,1]
-          float L[3];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) L[c] = a.light_mode == 1 ? a.light_vec[c] : a.light_vec[c] - pc[k][c];
-          float ln = sqrtf(fmaf(L[0], L[0], fmaf(L[1], L[1], L[2] * L[2])));
-          ln = ln > 1e-12f ? ln : 1e-12f;
-          const float dt = fmaf(nc[k][0] / nn, L[0] / ln, fmaf(nc[k][1] / nn, L[1] / ln, (nc[k][2] / nn) * (L[2] / ln)));
-          dv[k] = fminf(fmaxf(dt, 0.f), 1.f);
-        }
-      }
-      float base[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        p3[c] = fmaf(u, pc[0][c], fmaf(v, pc[1][c], w2 * pc[2][c]));
-        nrm[c] = fmaf(u, nc[0][c], fmaf(v, nc[1][c], w2 * nc[2][c]));
-      }
-      if (m.tex) {
-        int a0 = m.uv_idx[t * 3], a1 = m.uv_idx[t * 3 + 1], a2 = m.uv_idx[t * 3 + 2];
-        float tu = fmaf(u, m.uv[a0 * 2], fmaf(v, m.uv[a1 * 2], w2 * m.uv[a2 * 2]));
-        float tv = fmaf(u, m.uv[a0 * 2 + 1], fmaf(v, m.uv[a1 * 2 + 1], w2 * m.uv[a2 * 2 + 1]));
-        float x = tu * (float)m.texW - 0.5f, y = tv * (float)m.texH - 0.5f;
-        float fx0 = floorf(x), fy0 = floorf(y);
-        float fx = x - fx0, fy = y - fy0;
-        int x0 = (int)fx0 % m.texW;
-        if (x0 < 0) x0 += m.texW;
-        int y0 = (int)fy0 % m.texH;
-        if (y0 < 0) y0 += m.texH;
-        int x1 = (x0 + 1) % m.texW, y1 = (y0 + 1) % m.texH;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float t00 = m.tex[(y0 * m.texW + x0) * 3 + c], t10 = m.tex[(y0 * m.texW + x1) * 3 + c];
-          float t01 = m.tex[(y1 * m.texW + x0) * 3 + c], t11 = m.tex[(y1 * m.texW + x1) * 3 + c];
-          float ta = __fadd_rn(t00, __fmul_rn(fx, (t10 - t00)));
-          float tb = __fadd_rn(t01, __fmul_rn(fx, (t11 - t01)));
-          base[c] = __fadd_rn(ta, __fmul_rn(fy, (tb - ta)));
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          base[c] = fmaf(u, m.vcolor[i0 * 3 + c], fmaf(v, m.vcolor[i1 * 3 + c], w2 * m.vcolor[i2 * 3 + c]));
-      }
-      if (a.use_light) {
-        float d = fmaf(u, dv[0], fmaf(v, dv[1], w2 * dv[2]));
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-          base[c] = __fadd_rn(__fmul_rn(base[c], a.w_ambient), __fmul_rn(__fmul_rn(d, a.has_light_color ? a.light_color[c] : base[c]), a.w_diffuse));
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) col[c] = fminf(fmaxf(base[c], 0.f), 1.f);
-      float nn = sqrtf(fmaf(nrm[0], nrm[0], fmaf(nrm[1], nrm[1], nrm[2] * nrm[2])));
-      nn = nn > 1e-12f ? nn : 1e-12f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) nrm[c] = nrm[c] / nn;
-    }
     if (MODE == 0) {
       if (a.color) {
         a.color[o * 3] = col[0];
@@ -546,54 +516,206 @@ __global__ __launch_bounds__(RB_THREADS, RB_MINW) void render_kernel(RenderArgs 
       hv[7] = (f16)0.f;
       *reinterpret_cast<half8 *>(a.net_out + o * 8) = hv;
     }
+  };
+  for (int p0 = 0; p0 < npix; p0 += RB_THREADS) {
+    const int p = p0 + threadIdx.x;
+    const bool covered = p < npix && !(a.dbg & 2) && zbuf[p] != ~0ull;
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(covered);
+    if (mk != 0) {
+      int base = 0;
+      if (lane == __builtin_ctzll(mk)) base = atomicAdd(&covn, __builtin_popcountll(mk));
+      base = __shfl(base, __builtin_ctzll(mk));
+      if (covered) covq[base + __builtin_popcountll(mk & ((1ull << lane) - 1))] = (unsigned short)p;
+    }
+    if (p < npix && !covered) {
+      const float z3[3] = {0.f, 0.f, 0.f};
+      emit(p, z3, z3, z3);
+    }
+  }
+  __syncthreads();
+  const int ncov = covn;
+  for (int e = threadIdx.x; e < ncov; e += RB_THREADS) {
+    const int p = covq[e];
+    const int jl = p / Wo, i = p - jl * Wo;
+    const int j = row0 + jl;
+    const unsigned long long key = zbuf[p];
+    float col[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, p3[3] = {0, 0, 0};
+    {
+      int t = (int)(unsigned)(key & 0xffffffffull);
+      const int4 f4 = m.faces4[t];
+      const int i0 = f4.x, i1 = f4.y, i2 = f4.z;
+      const float4 rb0 = vbB[2 * i0], rb1 = vbB[2 * i1], rb2 = vbB[2 * i2];
+      const float4 rc0 = vbB[2 * i0 + 1], rc1 = vbB[2 * i1 + 1], rc2 = vbB[2 * i2 + 1];
+      const uint2 a0 = getA(i0), a1 = getA(i1), a2 = getA(i2);
+      float fa, b0, b1, b2;
+      float u, v, w2;
+      if (a0.x != RB_A_NONE && a1.x != RB_A_NONE && a2.x != RB_A_NONE) {      // the same integers in 32-bit arithmetic (see pass 1)
+        const int X0 = (short)(a0.x & 0xffffu), Y0 = (int)a0.x >> 16, X1 = (short)(a1.x & 0xffffu), Y1 = (int)a1.x >> 16,
+                  X2 = (short)(a2.x & 0xffffu), Y2 = (int)a2.x >> 16;
+        int area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+        const int sg = area > 0 ? 1 : -1;
+        area *= sg;
+        const int Px = 16 * i + 8, Py = 16 * j + 8;
+        const int e0 = sg * ((X2 - X1) * (Py - Y1) - (Y2 - Y1) * (Px - X1));
+        const int e1 = sg * ((X0 - X2) * (Py - Y2) - (Y0 - Y2) * (Px - X2));
+        const int e2 = sg * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
+        fa = (float)area;
+        b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+        float q0 = b0 / rc0.w, q1 = b1 / rc1.w, q2 = b2 / rc2.w;
+        float qs = (q0 + q1) + q2;
+        u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
+      } else {
+        const Vtx v0 = unpack(vc[i0]), v1 = unpack(vc[i1]), v2 = unpack(vc[i2]);
+        if (!(v0.ok && v1.ok && v2.ok)) {         // straddles the camera plane: weights from the homogeneous edge functions
+          float c[3][4];
+          const int id3[3] = {i0, i1, i2};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) clip_coords(m.pos, id3[k], M, c[k]);
+          const ClipTri T = clip_setup(c, hw, hh);
+          float l[3], zp;
+          (void)clip_eval(T, i, j, l, &zp);
+          const float ls = __fadd_rn(__fadd_rn(l[0], l[1]), l[2]);
+          u = __fdiv_rn(l[0], ls), v = __fdiv_rn(l[1], ls), w2 = (1.f - u) - v;
+        } else {
+          long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
+          long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
+          long long sg = area > 0 ? 1 : -1;
+          area *= sg;
+          long long Px = 16ll * i + 8, Py = 16ll * j + 8;
+          long long e0 = sg * ((X2 - X1) * (Py - Y1) - (Y2 - Y1) * (Px - X1));
+          long long e1 = sg * ((X0 - X2) * (Py - Y2) - (Y0 - Y2) * (Px - X2));
+          long long e2 = sg * ((X1 - X0) * (Py - Y0) - (Y1 - Y0) * (Px - X0));
+          fa = (float)area;
+          b0 = (float)e0 / fa, b1 = (float)e1 / fa, b2 = (float)e2 / fa;
+          float q0 = b0 / v0.w, q1 = b1 / v1.w, q2 = b2 / v2.w;
+          float qs = (q0 + q1) + q2;
+          u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
+        }
+      }
+      // camera-space position and Lambert term of the three vertices: the pre-pass' records
+      const float pc[3][3] = {{rb0.x, rb0.y, rb0.z}, {rb1.x, rb1.y, rb1.z}, {rb2.x, rb2.y, rb2.z}};
+      const float dv[3] = {rb0.w, rb1.w, rb2.w};
+      float nc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      if (MODE == 0) {
+        const int idx[3] = {i0, i1, i2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float nx = m.vnormals[idx[k] * 3], ny = m.vnormals[idx[k] * 3 + 1], nz = m.vnormals[idx[k] * 3 + 2];
+          nc[k][0] = fmaf(P0, nx, fmaf(P1, ny, P2 * nz));
+          nc[k][1] = fmaf(P4, nx, fmaf(P5, ny, P6 * nz));
+          nc[k][2] = fmaf(P8, nx, fmaf(P9, ny, P10 * nz));
+        }
+      }
+      float base[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        p3[c] = fmaf(u, pc[0][c], fmaf(v, pc[1][c], w2 * pc[2][c]));
+        nrm[c] = fmaf(u, nc[0][c], fmaf(v, nc[1][c], w2 * nc[2][c]));
+      }
+      if (m.tex) {
+        int a0 = m.uv_idx[t * 3], a1 = m.uv_idx[t * 3 + 1], a2 = m.uv_idx[t * 3 + 2];
+        float tu = fmaf(u, m.uv[a0 * 2], fmaf(v, m.uv[a1 * 2], w2 * m.uv[a2 * 2]));
+        float tv = fmaf(u, m.uv[a0 * 2 + 1], fmaf(v, m.uv[a1 * 2 + 1], w2 * m.uv[a2 * 2 + 1]));
+        float x = tu * (float)m.texW - 0.5f, y = tv * (float)m.texH - 0.5f;
+        float fx0 = floorf(x), fy0 = floorf(y);
+        float fx = x - fx0, fy = y - fy0;
+        int x0 = (int)fx0 % m.texW;
+        if (x0 < 0) x0 += m.texW;
+        int y0 = (int)fy0 % m.texH;
+        if (y0 < 0) y0 += m.texH;
+        int x1 = (x0 + 1) % m.texW, y1 = (y0 + 1) % m.texH;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float t00 = m.tex[(y0 * m.texW + x0) * 3 + c], t10 = m.tex[(y0 * m.texW + x1) * 3 + c];
+          float t01 = m.tex[(y1 * m.texW + x0) * 3 + c], t11 = m.tex[(y1 * m.texW + x1) * 3 + c];
+          float ta = __fadd_rn(t00, __fmul_rn(fx, (t10 - t00)));
+          float tb = __fadd_rn(t01, __fmul_rn(fx, (t11 - t01)));
+          base[c] = __fadd_rn(ta, __fmul_rn(fy, (tb - ta)));
+        }
+      } else {
+        base[0] = fmaf(u, rc0.x, fmaf(v, rc1.x, w2 * rc2.x));
+        base[1] = fmaf(u, rc0.y, fmaf(v, rc1.y, w2 * rc2.y));
+        base[2] = fmaf(u, rc0.z, fmaf(v, rc1.z, w2 * rc2.z));
+      }
+      if (a.use_light) {
+        float d = fmaf(u, dv[0], fmaf(v, dv[1], w2 * dv[2]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          base[c] = __fadd_rn(__fmul_rn(base[c], a.w_ambient), __fmul_rn(__fmul_rn(d, a.has_light_color ? a.light_color[c] : base[c]), a.w_diffuse));
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) col[c] = fminf(fmaxf(base[c], 0.f), 1.f);
+      float nn = sqrtf(fmaf(nrm[0], nrm[0], fmaf(nrm[1], nrm[1], nrm[2] * nrm[2])));
+      nn = nn > 1e-12f ? nn : 1e-12f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) nrm[c] = nrm[c] / nn;
+    }
+    emit(p, col, nrm, p3);
   }
 }
 
-// Strips per hypothesis and the scratch a launch needs: transformed vertices (16 B each), list counters, face lists (worst
-// case: every face in every strip).
+// Strips per hypothesis and the scratch a launch needs: the vertex records C (16 B), B (32 B) and A (8 B), the list counters and
+// the two face lists of every (hypothesis, strip) (worst case: every face in every strip).
 RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu) {
   RenderPlan p;
-  const size_t max_lds = 150 * 1024;
-  int rows_max = (int)(max_lds / ((size_t)Wo * 8));
+  const size_t budget = 148 * 1024;               // dynamic LDS of a workgroup
+  p.lds_verts = (size_t)V * 8 <= 64 * 1024 ? 1 : 0;                          // the hypothesis' A records beside the strip
+  p.a_lds = p.lds_verts ? (((size_t)V * 8 + 15) & ~(size_t)15) : 0;
+  int rows_max = (int)((budget - p.a_lds - 16) / ((size_t)Wo * 10));        // 8 B framebuffer + 2 B covered-pixel queue per pixel
   if (rows_max > Ho) rows_max = Ho;
   if (rows_max < 1) rows_max = 1;
   int S = (Ho + rows_max - 1) / rows_max;
-  // 40-row strips of a 160-row crop (50 KB: three workgroups per CU); thinner ones while the launch is still under two
-  // workgroups per CU - a workgroup's resolve pass shrinks with its strip, and the face lists keep the triangle pass from
-  // being repeated per strip (a pixel's result does not depend on the strip it is in)
+  // 40-row strips of a 160-row crop; thinner ones while the launch is still under one workgroup per CU (a workgroup's resolve
+  // pass shrinks with its strip)
   while (S < 4 && Ho / (S * 2) >= 8) S *= 2;
-  while ((size_t)N * S < (size_t)2 * num_cu && S < 16 && Ho / (S * 2) >= 8) S *= 2;
-  p.S = S;
+  while ((size_t)N * S * 2 <= (size_t)num_cu && S < 16 && Ho / (S * 2) >= 8) S *= 2;
   p.strip_rows = (Ho + S - 1) / S;
   p.S = (Ho + p.strip_rows - 1) / p.strip_rows;
-  p.vbuf_bytes = ((size_t)N * V * 16 + 255) & ~(size_t)255;
-  p.count_bytes = ((size_t)N * p.S * 4 + 255) & ~(size_t)255;
-  p.list_bytes = (size_t)N * p.S * F * 4;
-  p.total = p.vbuf_bytes + p.count_bytes + p.list_bytes;
+  p.lds_bytes = (size_t)p.strip_rows * Wo * 8 + ((((size_t)p.strip_rows * Wo * 2) + 15) & ~(size_t)15) + p.a_lds;
+  p.c_bytes = ((size_t)N * V * 16 + 255) & ~(size_t)255;
+  p.b_bytes = ((size_t)N * V * 32 + 255) & ~(size_t)255;
+  p.a_bytes = ((size_t)N * V * 8 + 255) & ~(size_t)255;
+  p.count_bytes = ((size_t)N * p.S * 16 + 255) & ~(size_t)255;
+  p.list_bytes = ((size_t)N * p.S * F * 4 + 255) & ~(size_t)255;
+  p.total = p.c_bytes + p.b_bytes + p.a_bytes + p.count_bytes + 2 * p.list_bytes;
   return p;
 }
 
-int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s) {
+int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
+  RenderArgs a = a_in;
+  static const int dbg_env = getenv("FP_RENDER_DBG") ? atoi(getenv("FP_RENDER_DBG")) : 0;      // timing experiments only (wrong images): 1 no per-lane rasterisation, 2 no resolve, 4 no triangle pass, 16 no per-wave rasterisation
+  a.dbg = dbg_env;
   FP_REQUIRE(a.N >= 0 && a.Ho > 0 && a.Wo > 0, "render: bad shape N=%d out=%dx%d", a.N, a.Ho, a.Wo);
   if (a.N == 0) return FP_OK;
-  FP_REQUIRE((size_t)a.Wo * 8 <= 150 * 1024, "render: output width %d too large for one LDS strip", a.Wo);
+  FP_REQUIRE((size_t)a.Wo * 10 <= 64 * 1024, "render: output width %d too large for one LDS strip", a.Wo);
+  FP_REQUIRE(a.mesh.F < (1 << 30), "render: %d faces", a.mesh.F);
   const RenderPlan pl = render_plan(a.N, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
+  FP_REQUIRE(pl.S <= RB_MAXS && pl.strip_rows * a.Wo <= 65535, "render: output %dx%d needs %d strips of %d pixels", a.Ho, a.Wo, pl.S, pl.strip_rows * a.Wo);
   FP_REQUIRE(a.scratch && a.scratch_bytes >= pl.total, "render: scratch of %zu bytes needed, %zu given", pl.total, a.scratch_bytes);
-  int4 *vbuf = (int4 *)a.scratch;
-  int *count = (int *)((char *)a.scratch + pl.vbuf_bytes);
-  int *list = (int *)((char *)a.scratch + pl.vbuf_bytes + pl.count_bytes);
-  const size_t lds = (size_t)pl.strip_rows * a.Wo * 8;
+  char *sc = (char *)a.scratch;
+  int4 *recC = (int4 *)sc;
+  float4 *recB = (float4 *)(sc + pl.c_bytes);
+  uint2 *recA = (uint2 *)(sc + pl.c_bytes + pl.b_bytes);
+  int *count = (int *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes);
+  unsigned *listA = (unsigned *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes + pl.count_bytes);
+  unsigned *listB = (unsigned *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes + pl.count_bytes + pl.list_bytes);
   ProfScope ps(ctx, s, "render", 0);
-  hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, vbuf, count, pl.S);
-  hipLaunchKernelGGL(bin_faces_kernel, dim3((a.mesh.F + 255) / 256, a.N), dim3(256), 0, s, a, (const int4 *)vbuf, count, list, pl.S, pl.strip_rows);
+  static bool set_c = false;
+  if (!set_c) {
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)classify_faces_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    set_c = true;
+  }
+  hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, recC, recB, recA);
+  hipLaunchKernelGGL(classify_faces_kernel, dim3(a.N), dim3(RB_THREADS), pl.a_lds, s, a, (const uint2 *)recA, count, listA, listB, pl.S, pl.strip_rows,
+                     pl.lds_verts);
   FP_CHECK_HIP(hipGetLastError());
   auto go = [&](auto kern, bool *attr_set) -> int {
     if (!*attr_set) {              // once per instantiation, for the largest strip: not a stream operation
-      FP_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      FP_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024));
       *attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * pl.S)), dim3(RB_THREADS), lds, s, a, pl.strip_rows, pl.S, (const int4 *)vbuf, (const int *)count,
-                       (const int *)list);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * pl.S)), dim3(RB_THREADS), pl.lds_bytes, s, a, pl.strip_rows, pl.S, (const int4 *)recC,
+                       (const float4 *)recB, (const uint2 *)recA, (const int *)count, (const unsigned *)listA, (const unsigned *)listB, pl.lds_verts);
     return FP_OK;
   };
   static bool set1 = false, set0 = false;
