@@ -95,6 +95,15 @@ def main():
   out['refine_rot'] = o['rot'].numpy()
   out['refine_encA3_sub'] = taps['encA3'][:, ::16, ::8, ::8].numpy()
   out['refine_encAB4_sub'] = taps['encAB4'][:, ::64, ::4, ::4].numpy()
+  # the same module under the reference's own inference precision (torch.cuda.amp.autocast, predict_pose_refine.py:190): fp16 autocast,
+  # here on the CPU backend.  What the HIP path is allowed to lose against the fp32 outputs is measured against what the reference's
+  # fp16 path loses (tests/test_gpu_pipeline.py::test_no_narrower_than_the_reference_autocast).
+  with torch.no_grad(), torch.autocast('cpu', dtype=torch.float16):
+    o16 = net(A, B)
+  out['refine_trans_ac16'] = o16['trans'].float().numpy()
+  out['refine_rot_ac16'] = o16['rot'].float().numpy()
+  out['refine_encA3_sub_ac16'] = taps['encA3'][:, ::16, ::8, ::8].float().numpy()
+  out['refine_encAB4_sub_ac16'] = taps['encAB4'][:, ::64, ::4, ::4].float().numpy()
 
   # ---- RefineNet without BN, 6d rotation head (non-default branches) --------------------------
   cfg2 = Cfg(use_BN=False, rot_rep='6d')
@@ -121,6 +130,9 @@ def main():
   out['score_logit_L8'] = so['score_logit'].numpy()
   out['score_logit_L4'] = so2['score_logit'].numpy()
   out['score_encAB4_sub'] = taps['s_encAB4'][:, ::64, ::4, ::4].numpy()
+  with torch.no_grad(), torch.autocast('cpu', dtype=torch.float16):          # predict_score.py:193
+    out['score_feats_ac16'] = snet.extract_feat(A3, B3).float().numpy()
+  out['score_encAB4_sub_ac16'] = taps['s_encAB4'][:, ::64, ::4, ::4].float().numpy()
 
   # ---- PositionalEmbedding buffer -----------------------------------------------------------------
   pe = PositionalEmbedding(d_model=512, max_len=400).pe

@@ -128,6 +128,29 @@ def test_score_net_vs_reference_golden(nets_gpu, golden):
     np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
 
 
+def test_no_narrower_than_the_reference_autocast(nets_gpu, golden):
+  """The precision claim of DESIGN.md section 2, pinned: the reference runs both networks under fp16 autocast
+  (predict_pose_refine.py:190, predict_score.py:193).  tests/golden/gen_golden.py ran the reference's own modules under
+  torch.autocast(fp16) next to the fp32 run; the HIP path - fp16 operands, fp32 accumulation, ONE extra fp16 rounding (the token
+  tensor) - must not be further from the reference's fp32 outputs than 2 x what the reference's fp16 path is, on the trunk tap, the
+  two heads and the ScoreNet features (rms over the fixture's elements).  The reference's fp16 error is printed beside ours."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  rms = lambda d: float(np.sqrt((np.asarray(d, dtype=np.float64) ** 2).mean()))
+  A, B = net_inputs(11, 8)
+  tap = _tokens_gpu(nets_gpu, nets_gpu['rnet'], A, B)[:, ::64, ::4, ::4].numpy()
+  trans, rot = _refine_gpu(nets_gpu, nets_gpu['rnet'], A, B)
+  A3, B3 = net_inputs(13, 8)
+  stap = _tokens_gpu(nets_gpu, nets_gpu['snet'], A3, B3)[:, ::64, ::4, ::4].numpy()
+  feats = torch.empty((8, 512), device='cuda')
+  check(lib().fp_score_features(nets_gpu['ctx'].handle, nets_gpu['snet'].handle, ptr(to_net_tensor(A3, B3)), 8, ptr(feats), stream_ptr()))
+  rows = (('encodeAB[4] tap', tap, 'refine_encAB4_sub'), ('trans head', trans.numpy(), 'refine_trans'), ('rot head', rot.numpy(), 'refine_rot'),
+          ('encoderAB[4] tap', stap, 'score_encAB4_sub'), ('ScoreNet features', feats.cpu().numpy(), 'score_feats'))
+  for what, got, key in rows:
+    ours, theirs = rms(got - golden[key]), rms(golden[key + '_ac16'] - golden[key])
+    print(f'{what}: rms |hip - ref fp32| = {ours:.2e}, rms |ref fp16 autocast - ref fp32| = {theirs:.2e} (ratio {ours / theirs:.2f})')
+    assert theirs > 0 and ours <= 2.0 * theirs, what
+
+
 def test_state_dict_errors(nets_gpu):
   from foundationpose_amd import _lib
   sd = dict(nets_gpu['rsd'])
