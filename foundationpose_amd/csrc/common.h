@@ -243,6 +243,15 @@ struct TokGemmArgs {
 };
 enum { TG_EPI_ROWS = 0, TG_EPI_VT = 1, TG_EPI_LN = 2, TG_EPI_LNSUM = 3 };
 int launch_tok_gemm(fp_ctx *ctx, const TokGemmArgs &a, int epi, hipStream_t s);
+// head_mlp.hip: out-projection + LayerNorm1 + linear1 + ReLU + linear2 + LayerNorm2 statistics of one transformer head in one launch
+struct HeadMlpArgs {
+  const f16 *att, *tok;        // [M][512]: attention output, residual tokens
+  int M;
+  const f16 *w_out, *w1, *w2;  // 512 x 512 in MFMA-fragment order (pack_tok_weights)
+  const float *b_out, *b1, *b2, *g1, *be1;
+  float *gsum;                 // [M/16][512] sums of the LayerNorm2-normalised rows over groups of 16 tokens
+};
+int launch_head_mlp(fp_ctx *ctx, const HeadMlpArgs &a, hipStream_t s);
 // Sum of `nparts` consecutive partial rows per hypothesis (fixed order) / T, gamma, beta, Linear(512 -> out_dim)
 int launch_mean_head(const float *partial, int nparts, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
                      int out_dim, float *out, hipStream_t s);

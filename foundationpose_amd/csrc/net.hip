@@ -441,16 +441,14 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
     // buffers and its own stream, so the tail of one head's kernels overlaps the other's (their launches are 3.08 rounds of
     // workgroups each)
     float *outs[2] = {d_trans + (size_t)s0 * 3, d_rot + (size_t)s0 * net->heads[1].out_dim};
-    f16 *qk[2], *vt[2], *att[2], *x1[2], *ff[2];
+    f16 *qk[2], *vt[2], *att[2];
     float *gsum[2];
     for (int h = 0; h < 2; ++h) {
       TAKE(qk_, f16, (size_t)M * 1024);
       TAKE(vt_, f16, (size_t)N * 4 * 128 * 416);
       TAKE(att_, f16, (size_t)M * 512);
-      TAKE(x1_, f16, (size_t)M * 512);
-      TAKE(ff_, f16, (size_t)M * 512);
       TAKE(gsum_, float, (size_t)(M / 16) * 512);
-      qk[h] = qk_, vt[h] = vt_, att[h] = att_, x1[h] = x1_, ff[h] = ff_, gsum[h] = gsum_;
+      qk[h] = qk_, vt[h] = vt_, att[h] = att_, gsum[h] = gsum_;
     }
     // in-projections of BOTH heads: the tokens are staged once per workgroup for 512 output columns of either head
     const LinP *q_[2] = {&net->heads[0].q, &net->heads[1].q}, *k_[2] = {&net->heads[0].k, &net->heads[1].k}, *v_[2] = {&net->heads[0].v, &net->heads[1].v};
@@ -462,29 +460,18 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
       const HeadW &H = net->heads[h];
       hipStream_t sh = h == 0 ? s : fo.stream_for(0);
       FP_TRY(launch_attention(ctx, qk[h], vt[h], N, 400, att[h], sh));
-      TokGemmArgs a;
-      memset(&a, 0, sizeof(a));
+      // x1 = norm1(tok + out_proj(att)); ff = relu(linear1(x1)); norm2(x1 + linear2(ff)) summed over groups of 16 tokens - one launch,
+      // x1 and ff stay in LDS (head_mlp.hip); then the mean over the 400 tokens + Linear(512, out_dim)
+      HeadMlpArgs a;
+      a.att = att[h];
+      a.tok = tok;
       a.M = M;
-      a.tokens = 400;
-      a.nblk = 1;
-      // x1 = norm1(tok + out_proj(att))
-      a.in = att[h];
-      a.blk[0] = TokGemmBlock{H.out.w, H.out.bias, x1[h], 512, 0, 0};
-      a.res = tok;
-      a.gamma = H.ln1g;
-      a.beta = H.ln1b;
-      FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_LN, sh));
-      // ff = relu(linear1(x1))
-      a.in = x1[h];
-      a.blk[0] = TokGemmBlock{H.ff1.w, H.ff1.bias, ff[h], 512, 0, 1};
-      a.res = nullptr;
-      FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_ROWS, sh));
-      // norm2(x1 + linear2(ff)) summed over groups of 16 tokens, then mean over the 400 tokens + Linear(512, out_dim)
-      a.in = ff[h];
-      a.blk[0] = TokGemmBlock{H.ff2.w, H.ff2.bias, nullptr, 512, 0, 0};
-      a.res = x1[h];
+      a.w_out = H.out.w, a.b_out = H.out.bias;
+      a.w1 = H.ff1.w, a.b1 = H.ff1.bias;
+      a.w2 = H.ff2.w, a.b2 = H.ff2.bias;
+      a.g1 = H.ln1g, a.be1 = H.ln1b;
       a.gsum = gsum[h];
-      FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_LNSUM, sh));
+      FP_TRY(launch_head_mlp(ctx, a, sh));
       FP_TRY(launch_mean_head(gsum[h], 25, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], sh));
     }
     FP_TRY(fo.join());
@@ -533,6 +520,42 @@ extern "C" int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const f
     return FP_OK;
   };
   rc = run();
+  (void)hipFree(dev);
+  return rc;
+}
+
+// Building block for the parity tests: the fused post-attention part of one transformer head (head_mlp.hip).
+extern "C" int fp_head_mlp_f16(fp_ctx *ctx, const void *d_att, const void *d_tok, int M, const float *h_w_out, const float *h_b_out,
+                               const float *h_gamma1, const float *h_beta1, const float *h_w1, const float *h_b1, const float *h_w2,
+                               const float *h_b2, float *d_gsum, void *stream) {
+  FP_REQUIRE(ctx && d_att && d_tok && h_w_out && h_b_out && h_gamma1 && h_beta1 && h_w1 && h_b1 && h_w2 && h_b2 && d_gsum, "fp_head_mlp_f16: null argument");
+  FP_CHECK_HIP(hipSetDevice(ctx->device));
+  const size_t wh = (size_t)512 * 512;
+  std::vector<f16> hw(3 * wh);
+  pack_tok_weights(h_w_out, hw.data());
+  pack_tok_weights(h_w1, hw.data() + wh);
+  pack_tok_weights(h_w2, hw.data() + 2 * wh);
+  std::vector<float> hv(5 * 512);
+  const float *src[5] = {h_b_out, h_b1, h_b2, h_gamma1, h_beta1};
+  for (int i = 0; i < 5; ++i) memcpy(hv.data() + i * 512, src[i], 512 * sizeof(float));
+  char *dev = nullptr;
+  FP_CHECK_HIP(hipMalloc((void **)&dev, hw.size() * 2 + hv.size() * 4));
+  auto run = [&]() -> int {
+    FP_CHECK_HIP(hipMemcpy(dev, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    float *dv = (float *)(dev + hw.size() * 2);
+    FP_CHECK_HIP(hipMemcpy(dv, hv.data(), hv.size() * 4, hipMemcpyHostToDevice));
+    HeadMlpArgs a;
+    a.att = (const f16 *)d_att;
+    a.tok = (const f16 *)d_tok;
+    a.M = M;
+    a.w_out = (const f16 *)dev, a.w1 = (const f16 *)dev + wh, a.w2 = (const f16 *)dev + 2 * wh;
+    a.b_out = dv, a.b1 = dv + 512, a.b2 = dv + 1024, a.g1 = dv + 1536, a.be1 = dv + 2048;
+    a.gsum = d_gsum;
+    FP_TRY(launch_head_mlp(ctx, a, (hipStream_t)stream));
+    FP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return FP_OK;
+  };
+  const int rc = run();
   (void)hipFree(dev);
   return rc;
 }

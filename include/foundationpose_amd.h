@@ -215,6 +215,15 @@ int fp_attention_f16(fp_ctx *ctx, const void *d_qk, const void *d_vt, int B, int
 int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const float *h_weight, const float *h_bias, int epilogue, int relu,
                         const void *d_res, const float *h_gamma, const float *h_beta, int tokens, void *d_out, void *stream);
 
+/* Building block: the part of one nn.TransformerEncoderLayer behind its attention core as the RefineNet heads run it, in one launch
+ * (refine_network.py:56-70,88-91): x1 = LayerNorm1(tok + att W_out^T + b_out); ff = relu(x1 W1^T + b1); y = LayerNorm2(x1 + ff W2^T + b2)
+ * WITHOUT its gamma / beta; d_gsum [M/16][512] fp32 = sums of y over groups of 16 tokens (the token mean, gamma2 / beta2 and the
+ * output Linear follow in fp_refine_forward).  d_att / d_tok fp16 [M][512], M a multiple of 16; weights host fp32 row-major
+ * (512x512) / (512); synchronises the stream. */
+int fp_head_mlp_f16(fp_ctx *ctx, const void *d_att, const void *d_tok, int M, const float *h_w_out, const float *h_b_out,
+                    const float *h_gamma1, const float *h_beta1, const float *h_w1, const float *h_b1, const float *h_w2,
+                    const float *h_b2, float *d_gsum, void *stream);
+
 /* mycpp.cluster_poses (mycpp/src/app/pybind_api.cpp:24-68); host function, float32 row-major 4x4.
  * h_out must hold n_in*16 floats; returns the number of kept poses (>=1) or a negative error. */
 int fp_cluster_poses(float angle_diff_deg, float dist_diff_m, const float *h_poses_in, int n_in, const float *h_symmetry_tfs,

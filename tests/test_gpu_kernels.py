@@ -568,3 +568,52 @@ def test_register_prelude_on_device(sc, fp, golden):
   z = np.zeros_like(dfull)
   st = U.mask_depth_stats(torch.from_numpy(z).cuda(), sc['mask'])
   assert st['n_usable'] == 0 and st['n_mask'] == sc['mask'].sum() and st['median'] == 0
+
+
+@pytest.mark.parametrize('n_hyp', [3, 1, 7])
+def test_head_mlp_vs_fp32_reference(fp, n_hyp):
+  """csrc/head_mlp.hip - out-projection + LayerNorm1 + linear1 + ReLU + linear2 + LayerNorm2 sums of one RefineNet head in one launch
+  (refine_network.py:56-70,88-91) - against torch fp32 on the same fp16-rounded operands, with x1 and ff rounded to fp16 where the
+  kernel rounds them (they are GEMM operands: fp16 in the reference's autocast too).  M = 400 n: 1200 and 2800 tokens end in a ragged
+  64-token tile.  Also: a hypothesis' result does not depend on its place in the batch (bit-exact), and the fused launch agrees with
+  the three unfused tok_gemm launches it replaces to fp32 summation order."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  M = 400 * n_hyp
+  g = torch.Generator().manual_seed(300 + n_hyp)
+  att = torch.randn((M, 512), generator=g).half()
+  tok = (torch.randn((M, 512), generator=g) * 2 + 0.5).half()
+  mk = lambda: (torch.randn((512, 512), generator=g) * (1.0 / 512) ** 0.5).half().float()
+  w_out, w1, w2 = mk(), mk(), mk()
+  b_out, b1, b2 = (torch.randn((512,), generator=g) * 0.1 for _ in range(3))
+  gam, bet = torch.rand((512,), generator=g) + 0.5, torch.randn((512,), generator=g) * 0.1
+  x1 = torch.nn.functional.layer_norm(tok.float() + att.float() @ w_out.T + b_out, (512,), gam, bet, 1e-5).half().float()
+  ff = torch.relu(x1 @ w1.T + b1).half().float()
+  y = torch.nn.functional.layer_norm(x1 + ff @ w2.T + b2, (512,), None, None, 1e-5)
+  ref = y.reshape(M // 16, 16, 512).sum(1)
+  att_d, tok_d = att.cuda(), tok.cuda()
+  args = [ptr(t.numpy()) for t in (w_out, b_out, gam, bet, w1, b1, w2, b2)]
+
+  def run(a_d, t_d, m):
+    out = torch.full((m // 16, 512), float('nan'), dtype=torch.float32, device='cuda')
+    check(lib().fp_head_mlp_f16(fp['ctx'].handle, ptr(a_d), ptr(t_d), m, *args, ptr(out), stream_ptr()))
+    return out
+  got = run(att_d, tok_d, M)
+  # x1 / ff are rounded to fp16 on both sides, but a value that sits on a rounding boundary may round differently (the fp32 sums
+  # differ in their last bits): one fp16 ulp of one operand moves a 512-term dot product by ~1e-3 of an O(1) normalised value
+  err = float((got.cpu() - ref).abs().max())
+  print(f'head_mlp M={M}: max |gsum - ref| = {err:.2e} on values of magnitude {float(ref.abs().max()):.1f}')
+  assert err <= 2.5e-3 * float(ref.abs().max()) + 1e-3, err
+  if n_hyp > 1:
+    one = run(att[400:800].contiguous().cuda(), tok[400:800].contiguous().cuda(), 400)
+    assert torch.equal(one, got[25:50])
+  # the three launches it replaces (tok_gemm.hip): same values up to the fp32 summation order of the LayerNorm statistics
+  def lin(x_d, w, b, epi, relu, res_d, ln, out):
+    check(lib().fp_token_linear_f16(fp['ctx'].handle, ptr(x_d), M, ptr(w.numpy()), ptr(b.numpy()), epi, relu, ptr(res_d) if res_d is not None else None,
+                                    ptr(gam.numpy()) if ln else None, ptr(bet.numpy()) if ln else None, 400, ptr(out), stream_ptr()))
+    return out
+  x1_d = lin(att_d, w_out, b_out, 2, 0, tok_d, True, torch.empty((M, 512), dtype=torch.float16, device='cuda'))
+  ff_d = lin(x1_d, w1, b1, 0, 1, None, False, torch.empty((M, 512), dtype=torch.float16, device='cuda'))
+  gs_d = lin(ff_d, w2, b2, 3, 0, x1_d, False, torch.empty((M // 16, 512), dtype=torch.float32, device='cuda'))
+  d = float((gs_d - got).abs().max())
+  print(f'head_mlp M={M}: max |fused - three launches| = {d:.2e}')
+  assert d <= 2.5e-3 * float(ref.abs().max()) + 1e-3
