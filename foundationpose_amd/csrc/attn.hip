@@ -318,17 +318,25 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
     for (int i = 0; i < 32; ++i) o[i] = st[i];
   }
 #endif
-  // O^T accumulator: col = query lr, row = dim (r&3) + 8*(r>>2) + 4*lh of each 32-dim tile -> 8-byte stores
-  if (q < T) {
+  // O^T accumulator: col = query lr, row = dim (r&3) + 8*(r>>2) + 4*lh of each 32-dim tile: a query's output row is split across
+  // the two halves of the wave (lane: dims 8g .. 8g+3, lane + 32: 8g+4 .. 8g+7).  One v_permlane32_swap per dword and pair of
+  // dim groups (g, g+1) leaves lanes 0-31 with dims 8g .. 8g+7 and lanes 32-63 with 8g+8 .. 8g+15: 8 16-byte stores per lane instead
+  // of 16 8-byte ones (the store tail is issue-bound: cdna_hip_programming.md T21).  The swaps need every lane: only the store is masked.
+  {
     const float inv = 1.f / l_run;
+    f16 *orow = out + (rowbase + min(q, T - 1)) * 512 + h * AT_DH + lh * 8;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        half4 hv;
+      for (int gq = 0; gq < 4; gq += 2) {
+        half4 ha, hb;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hv[j] = (f16)(oacc[dt][gq * 4 + j] * inv);
-        *reinterpret_cast<half4 *>(out + (rowbase + q) * 512 + h * AT_DH + dt * 32 + gq * 8 + lh * 4) = hv;
+        for (int j = 0; j < 4; ++j) ha[j] = (f16)(oacc[dt][gq * 4 + j] * inv), hb[j] = (f16)(oacc[dt][(gq + 1) * 4 + j] * inv);
+        const uint2 ua = __builtin_bit_cast(uint2, ha), ub = __builtin_bit_cast(uint2, hb);
+        const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+        const uint4 v = {r0[0], r1[0], r0[1], r1[1]};
+        if (q < T) *reinterpret_cast<uint4 *>(orow + dt * 32 + gq * 8) = v;
       }
   }
 }

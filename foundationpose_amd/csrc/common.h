@@ -288,6 +288,7 @@ struct RenderArgs {
 };
 struct RenderPlan {
   int S, strip_rows, lds_verts;         // strips per hypothesis, rows per strip, whether the triangle pass keeps the vertex records in LDS
+  int G, Fg;                            // face ranges per hypothesis in the classification, faces per range
   size_t lds_bytes, a_lds, c_bytes, b_bytes, a_bytes, count_bytes, list_bytes, total;
 };
 RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu);

@@ -229,31 +229,35 @@ __global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 
 
 // Per (hypothesis, strip) face lists.  A face is dropped here exactly when it cannot touch a pixel of the crop (pixel range empty
 // after clamping to the crop, or zero area): the same integers as in the triangle pass, so the images are bit-identical to a walk
-// over all faces.  count[(b*S + s)*4 + {0,1,2}] = small, medium, list-B entries; listA[(b*S + s)*F ..]: small from the front,
-// medium from the back; listB: large 32-bit triangles and RB_SLOW ones.
+// over all faces.  The faces of a hypothesis are cut into G contiguous ranges of Fg, one workgroup each (G = 1 from 64 hypotheses on;
+// a handful of hypotheses - tracking - would otherwise leave the classification to a handful of workgroups).  Per (hypothesis b, strip s,
+// range g): count[((b*S + s)*G + g)*4 + {0,1,2}] = small, medium, list-B entries; listA[(b*S + s)*G*Fg + g*Fg ..]: small from the
+// front of the range's segment, medium from its back; listB likewise: large 32-bit triangles and RB_SLOW ones.
 __global__ __launch_bounds__(RB_THREADS) void classify_faces_kernel(RenderArgs a, const uint2 *__restrict__ recA, int *__restrict__ count,
                                                                    unsigned *__restrict__ listA, unsigned *__restrict__ listB, int S, int strip_rows,
-                                                                   int lds_verts) {
+                                                                   int lds_verts, int G, int Fg) {
   extern __shared__ __attribute__((aligned(16))) uint2 cl_ldsA[];
   __shared__ int cs[RB_MAXS + 1][3];
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, grp = blockIdx.y;
   const MeshDev &m = a.mesh;
   const uint2 *gA = recA + (size_t)b * m.V;
+  const int f0 = grp * Fg, f1 = min(m.F, f0 + Fg);
   for (int i = threadIdx.x; i < S * 3; i += RB_THREADS) cs[i / 3][i % 3] = 0;
   if (lds_verts)
     for (int i = threadIdx.x; i < m.V; i += RB_THREADS) cl_ldsA[i] = gA[i];
   __syncthreads();
   auto getA = [&](int i) -> uint2 { return lds_verts ? cl_ldsA[i] : gA[i]; };
-  unsigned *lA = listA + (size_t)b * S * m.F, *lB = listB + (size_t)b * S * m.F;
+  const size_t seg = (size_t)G * Fg;                     // list entries per (hypothesis, strip)
+  unsigned *lA = listA + (size_t)b * S * seg + (size_t)grp * Fg, *lB = listB + (size_t)b * S * seg + (size_t)grp * Fg;
   int4 f_n = make_int4(0, 0, 0, 0);
-  if ((int)threadIdx.x < m.F) f_n = m.faces4[threadIdx.x];
-  for (int t = threadIdx.x; t < m.F; t += RB_THREADS) {
+  if (f0 + (int)threadIdx.x < f1) f_n = m.faces4[f0 + threadIdx.x];
+  for (int t = f0 + threadIdx.x; t < f1; t += RB_THREADS) {
     const int4 f = f_n;
-    if (t + RB_THREADS < m.F) f_n = m.faces4[t + RB_THREADS];
+    if (t + RB_THREADS < f1) f_n = m.faces4[t + RB_THREADS];
     const uint2 a0 = getA(f.x), a1 = getA(f.y), a2 = getA(f.z);
     if (a0.x == RB_A_NONE || a1.x == RB_A_NONE || a2.x == RB_A_NONE) {
       // cannot be bounded here: every strip looks at it (faces entirely behind the camera are dropped there)
-      for (int sI = 0; sI < S; ++sI) lB[(size_t)sI * m.F + atomicAdd(&cs[sI][2], 1)] = (unsigned)t | RB_SLOW;
+      for (int sI = 0; sI < S; ++sI) lB[(size_t)sI * seg + atomicAdd(&cs[sI][2], 1)] = (unsigned)t | RB_SLOW;
       continue;
     }
     const int X0 = (short)(a0.x & 0xffffu), Y0 = (int)a0.x >> 16, X1 = (short)(a1.x & 0xffffu), Y1 = (int)a1.x >> 16,
@@ -268,19 +272,19 @@ __global__ __launch_bounds__(RB_THREADS) void classify_faces_kernel(RenderArgs a
     for (int sI = ja / strip_rows; sI <= jb / strip_rows; ++sI) {
       const int rows = min(jb, (sI + 1) * strip_rows - 1) - max(ja, sI * strip_rows) + 1;
       const int nc = bw * rows;
-      if (nc <= RB_SMALL) lA[(size_t)sI * m.F + atomicAdd(&cs[sI][0], 1)] = (unsigned)t;
-      else if (nc <= RB_MEDIUM) lA[(size_t)sI * m.F + (m.F - 1 - atomicAdd(&cs[sI][1], 1))] = (unsigned)t;
-      else lB[(size_t)sI * m.F + atomicAdd(&cs[sI][2], 1)] = (unsigned)t;
+      if (nc <= RB_SMALL) lA[(size_t)sI * seg + atomicAdd(&cs[sI][0], 1)] = (unsigned)t;
+      else if (nc <= RB_MEDIUM) lA[(size_t)sI * seg + (Fg - 1 - atomicAdd(&cs[sI][1], 1))] = (unsigned)t;
+      else lB[(size_t)sI * seg + atomicAdd(&cs[sI][2], 1)] = (unsigned)t;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < S * 3; i += RB_THREADS) count[((size_t)b * S + i / 3) * 4 + i % 3] = cs[i / 3][i % 3];
+  for (int i = threadIdx.x; i < S * 3; i += RB_THREADS) count[(((size_t)b * S + i / 3) * G + grp) * 4 + i % 3] = cs[i / 3][i % 3];
 }
 
 template <int MODE>
 __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int strip_rows, int n_strips, const int4 *__restrict__ recC,
                                                             const float4 *__restrict__ recB, const uint2 *__restrict__ recA, const int *__restrict__ count,
-                                                            const unsigned *__restrict__ listA, const unsigned *__restrict__ listB, int lds_verts) {
+                                                            const unsigned *__restrict__ listA, const unsigned *__restrict__ listB, int lds_verts, int G, int Fg) {
   // dynamic LDS: the strip (8 B per pixel), the queue of its covered pixels (2 B per pixel), then (lds_verts) the hypothesis' A records
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];
   __shared__ float sM[16];
@@ -322,9 +326,10 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     return o;
   };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int *cnt = count + ((size_t)b * n_strips + strip) * 4;
+  for (int grp = 0; grp < G; ++grp) {             // the face ranges the classification was cut into (one from 64 hypotheses on)
+  const int *cnt = count + (((size_t)b * n_strips + strip) * G + grp) * 4;
   const int n_small = (a.dbg & 4) ? 0 : cnt[0], n_med = (a.dbg & 4) ? 0 : cnt[1], n_b = (a.dbg & 20) ? 0 : cnt[2];
-  const unsigned *lA = listA + ((size_t)b * n_strips + strip) * m.F, *lB = listB + ((size_t)b * n_strips + strip) * m.F;
+  const unsigned *lA = listA + ((size_t)b * n_strips + strip) * G * Fg + (size_t)grp * Fg, *lB = listB + ((size_t)b * n_strips + strip) * G * Fg + (size_t)grp * Fg;
 
   // ---- pass 1a, per lane: the small and medium triangles of this strip, 32-bit edge functions.  |X|,|Y| < 2^14 -> differences
   // < 2^15, products < 2^30, sums < 2^31: the same integers as the 64-bit form below, so coverage, barycentrics and depth keys
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   // entry's index quad is requested one iteration ahead.
   {
     const int n_a = n_small + n_med;
-    auto entry = [&](int e) -> int { return (int)(e < n_small ? lA[e] : lA[m.F - 1 - (e - n_small)]); };
+    auto entry = [&](int e) -> int { return (int)(e < n_small ? lA[e] : lA[Fg - 1 - (e - n_small)]); };
     int t_n = 0;
     int4 f_n = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x < n_a) {
@@ -460,6 +465,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
         atomicMin(&zbuf[(int)(j - row0) * Wo + (int)i], key);
       }
     }
+  }
   }
   __syncthreads();
 
@@ -675,8 +681,11 @@ RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu) {
   p.c_bytes = ((size_t)N * V * 16 + 255) & ~(size_t)255;
   p.b_bytes = ((size_t)N * V * 32 + 255) & ~(size_t)255;
   p.a_bytes = ((size_t)N * V * 8 + 255) & ~(size_t)255;
-  p.count_bytes = ((size_t)N * p.S * 16 + 255) & ~(size_t)255;
-  p.list_bytes = ((size_t)N * p.S * F * 4 + 255) & ~(size_t)255;
+  p.G = 1;                                        // face ranges per hypothesis in the classification: more while it would fill < 1/4 of the chip
+  while ((size_t)N * p.G * 4 <= (size_t)num_cu && p.G < 8 && F / (p.G * 2) >= 1024) p.G *= 2;
+  p.Fg = (F + p.G - 1) / p.G;
+  p.count_bytes = ((size_t)N * p.S * p.G * 16 + 255) & ~(size_t)255;
+  p.list_bytes = ((size_t)N * p.S * p.G * p.Fg * 4 + 255) & ~(size_t)255;
   p.total = p.c_bytes + p.b_bytes + p.a_bytes + p.count_bytes + 2 * p.list_bytes;
   return p;
 }
@@ -706,8 +715,8 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
     set_c = true;
   }
   hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, recC, recB, recA);
-  hipLaunchKernelGGL(classify_faces_kernel, dim3(a.N), dim3(RB_THREADS), pl.a_lds, s, a, (const uint2 *)recA, count, listA, listB, pl.S, pl.strip_rows,
-                     pl.lds_verts);
+  hipLaunchKernelGGL(classify_faces_kernel, dim3(a.N, pl.G), dim3(RB_THREADS), pl.a_lds, s, a, (const uint2 *)recA, count, listA, listB, pl.S, pl.strip_rows,
+                     pl.lds_verts, pl.G, pl.Fg);
   FP_CHECK_HIP(hipGetLastError());
   auto go = [&](auto kern, bool *attr_set) -> int {
     if (!*attr_set) {              // once per instantiation, for the largest strip: not a stream operation
@@ -715,7 +724,8 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
       *attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * pl.S)), dim3(RB_THREADS), pl.lds_bytes, s, a, pl.strip_rows, pl.S, (const int4 *)recC,
-                       (const float4 *)recB, (const uint2 *)recA, (const int *)count, (const unsigned *)listA, (const unsigned *)listB, pl.lds_verts);
+                       (const float4 *)recB, (const uint2 *)recA, (const int *)count, (const unsigned *)listA, (const unsigned *)listB, pl.lds_verts, pl.G,
+                       pl.Fg);
     return FP_OK;
   };
   static bool set1 = false, set0 = false;

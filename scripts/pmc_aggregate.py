@@ -5,7 +5,7 @@ FETCH_SIZE / WRITE_SIZE are reported in KB.  On gfx950 FETCH_SIZE counts a 128-b
 it is doubled here (MI355X_MICROARCH.md); WRITE_SIZE is taken as is.  Infinity-Cache hits are part of FETCH_SIZE, so the sum
 is fabric (L2-miss) traffic - an upper bound on HBM bytes."""
 import collections, csv, glob, json, os
-ROUND = os.environ.get('ROUND', 'r02')
+ROUND = os.environ.get('ROUND', 'r03')
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -18,7 +18,7 @@ def load(kind, counter):
   return agg
 
 
-HEAD_KERNELS = ('tok_gemm', 'attention_kernel', 'mean_head', 'vt_pad_zero', 'layernorm', 'ln_partial', 'token_mean', 'conv_igemm2_kernelILi128ELi1', 'conv_igemm2_kernelILi64ELi1')
+HEAD_KERNELS = ('tok_gemm', 'head_mlp', 'attention_kernel', 'mean_head', 'vt_pad_zero', 'layernorm', 'ln_partial', 'token_mean', 'conv_igemm2_kernelILi128ELi1', 'conv_igemm2_kernelILi64ELi1')
 
 
 def chain_bytes(rows):
@@ -37,13 +37,16 @@ def head_chain(rows):
   11 head passes (2 heads x 5 refine iterations + ScoreNet's attention), this round against the committed round-1 profile."""
   now = chain_bytes(rows)
   before = {}
-  old = os.path.join(REPO, 'profiles', 'r01_pmc_hbm_traffic.csv')
-  if os.path.exists(old):
-    before = chain_bytes([(r['kernel'], r['grid_threads'], r['launches'], r['FETCH_SIZE_KB_raw_mean'], r['fetch_MB_corrected_x2'], r['WRITE_SIZE_MB_mean'])
-                          for r in csv.DictReader(open(old))])
+  prev = {}
+  for tag in ('r01', 'r02'):
+    old = os.path.join(REPO, 'profiles', tag + '_pmc_hbm_traffic.csv')
+    if os.path.exists(old) and tag != ROUND:
+      prev[tag] = chain_bytes([(r['kernel'], r['grid_threads'], r['launches'], r['FETCH_SIZE_KB_raw_mean'], r['fetch_MB_corrected_x2'], r['WRITE_SIZE_MB_mean'])
+                               for r in csv.DictReader(open(old))])
+  before = prev.get('r02') or prev.get('r01') or {}
   js = {'unit': 'bytes per bench step (fetch x2-corrected + write), 11 head passes', 'this_round': now, 'this_round_total': sum(now.values()),
-        'round1': before, 'round1_total': sum(before.values()),
-        'ratio': (sum(now.values()) / sum(before.values())) if before else None}
+        'previous_rounds': {k: {'kernels': v, 'total': sum(v.values())} for k, v in prev.items()},
+        'ratio_to_previous_round': (sum(now.values()) / sum(before.values())) if before else None}
   json.dump(js, open(os.path.join(REPO, 'profiles', f'{ROUND}_head_chain_traffic.json'), 'w'), indent=1)
   print(json.dumps(js, indent=1))
 
