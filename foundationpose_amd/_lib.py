@@ -81,6 +81,7 @@ _PROTOS = {
   'fp_cluster_poses': (c_int, [c_float, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p]),
   'fp_prof_enable': (c_int, [c_void_p, c_int]),
   'fp_prof_read': (c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
+  'fp_prof_read_busy': (c_int, [c_void_p, c_char_p, POINTER(c_double)]),
   'fp_prof_reset': (c_int, [c_void_p]),
 }
 
@@ -175,7 +176,9 @@ class Context:
   def prof_read(self, cls_name):
     ms, n, fl = c_double(), c_int64(), c_double()
     check(lib().fp_prof_read(self.handle, cls_name.encode(), byref(ms), byref(n), byref(fl)))
-    return dict(total_ms=ms.value, launches=n.value, flops=fl.value)
+    busy = c_double()
+    check(lib().fp_prof_read_busy(self.handle, cls_name.encode(), byref(busy)))
+    return dict(total_ms=ms.value, launches=n.value, flops=fl.value, busy_ms=busy.value)
 
 
 class DeviceMesh:

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
+#include <algorithm>
 
 static thread_local char g_err[1024] = "";
 
@@ -91,6 +92,7 @@ extern "C" int fp_ctx_destroy(fp_ctx *ctx) {
     (void)hipEventDestroy(e.b);
   }
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  if (ctx->ev_ref) (void)hipEventDestroy(ctx->ev_ref);
   if (ctx->side_ready) {
     for (int i = 0; i < fp_ctx::NSIDE; ++i) {
       (void)hipStreamDestroy(ctx->side[i]);
@@ -125,18 +127,27 @@ extern "C" int fp_ctx_reserve(fp_ctx *ctx, int max_hyp) {
 }
 
 // ---- profiling ---------------------------------------------------------------------------------
+static int prof_drain(fp_ctx *ctx);
+
 extern "C" int fp_prof_enable(fp_ctx *ctx, int on) {
   FP_REQUIRE(ctx, "fp_prof_enable: null ctx");
   ctx->prof = on < 0 ? 0 : (on > 2 ? 2 : on);
+  if (ctx->prof) {                            // the time origin of the launch spans (fp_prof_read_busy), renewed whenever profiling is
+    FP_TRY(prof_drain(ctx));                  // switched on: the spans are float32 milliseconds since then
+    if (!ctx->ev_ref) FP_CHECK_HIP(hipEventCreate(&ctx->ev_ref));
+    FP_CHECK_HIP(hipEventRecord(ctx->ev_ref, nullptr));
+    FP_CHECK_HIP(hipEventSynchronize(ctx->ev_ref));
+  }
   return FP_OK;
 }
 
 static int prof_drain(fp_ctx *ctx) {
   for (auto &e : ctx->pending) {
     FP_CHECK_HIP(hipEventSynchronize(e.b));
-    float ms = 0.f;
+    float ms = 0.f, t0 = 0.f;
     FP_CHECK_HIP(hipEventElapsedTime(&ms, e.a, e.b));
     ProfEntry &p = ctx->prof_tab[e.cls];
+    if (ctx->ev_ref && hipEventElapsedTime(&t0, ctx->ev_ref, e.a) == hipSuccess) p.spans.emplace_back(t0, t0 + ms);
     p.total_ms += ms;
     p.flops += e.flops;
     p.launches += 1;
@@ -155,6 +166,33 @@ extern "C" int fp_prof_read(fp_ctx *ctx, const char *cls, double *total_ms, int6
   if (total_ms) *total_ms = e.total_ms;
   if (launches) *launches = e.launches;
   if (flops) *flops = e.flops;
+  return FP_OK;
+}
+
+// Time during which AT LEAST ONE launch of the class was executing (the union of the launch spans): equal to total_ms when the
+// launches follow one another, smaller when launches of the class overlap - the two half-batch trunks on two streams, the two
+// RefineNet heads.  FLOPs / busy time is the rate the chip sustains on the class.
+extern "C" int fp_prof_read_busy(fp_ctx *ctx, const char *cls, double *busy_ms) {
+  FP_REQUIRE(ctx && cls && busy_ms, "fp_prof_read_busy: null argument");
+  FP_TRY(prof_drain(ctx));
+  *busy_ms = 0.0;
+  auto it = ctx->prof_tab.find(cls);
+  if (it == ctx->prof_tab.end()) return FP_OK;
+  std::vector<std::pair<float, float>> v = it->second.spans;
+  std::sort(v.begin(), v.end());
+  double busy = 0.0;
+  float cur_a = 0.f, cur_b = -1.f;
+  for (const auto &sp : v) {
+    if (cur_b < cur_a || sp.first > cur_b) {
+      if (cur_b >= cur_a) busy += cur_b - cur_a;
+      cur_a = sp.first;
+      cur_b = sp.second;
+    } else if (sp.second > cur_b) {
+      cur_b = sp.second;
+    }
+  }
+  if (cur_b >= cur_a) busy += cur_b - cur_a;
+  *busy_ms = busy;
   return FP_OK;
 }
 

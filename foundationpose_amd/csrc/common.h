@@ -56,6 +56,7 @@ struct fp_mesh {
 struct ProfEntry {
   double total_ms = 0, flops = 0;
   int64_t launches = 0;
+  std::vector<std::pair<float, float>> spans;   // (start, end) of every launch in ms since fp_ctx::ev_ref: launches of one class may overlap (two streams)
 };
 
 struct PendingEvent {
@@ -85,6 +86,7 @@ struct fp_ctx {
   std::map<std::string, ProfEntry> prof_tab;
   std::vector<PendingEvent> pending;
   std::vector<hipEvent_t> ev_pool;   // recycled timing events: a profiled launch costs two hipEventRecord, no create / destroy
+  hipEvent_t ev_ref = nullptr;       // time origin of the launch spans, recorded when profiling is switched on
   int num_cu = 256;
   void *zero_page = nullptr;   // 4 KB of zeros: DMA source for out-of-image taps
   // side streams for the per-object stages (crop window, render, observed crop) of a multi-object pass: with 8 objects

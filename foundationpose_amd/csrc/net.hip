@@ -348,7 +348,7 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
   }
 
 // shared trunk -> tokens (N*400, 512) fp16, positional embedding added
-int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int N, f16 **tokens_out, hipStream_t s) {
+int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int N, f16 **tokens_out, hipStream_t s, f16 *tok_dst = nullptr) {
   const ConvW *t = net->trunk;
   const size_t n2 = (size_t)2 * N;
   TAKE(a0, f16, n2 * 80 * 80 * 64);
@@ -361,7 +361,11 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
   TAKE(c0, f16, (size_t)N * 400 * 512);
   TAKE(tC, f16, (size_t)N * 400 * 512);
   TAKE(c1, f16, (size_t)N * 400 * 512);
-  TAKE(tok, f16, (size_t)N * 400 * 512);
+  f16 *tok = tok_dst;                  // (given by the caller when the batch is cut in two: both halves write into one token tensor)
+  if (!tok) {
+    TAKE(tok_, f16, (size_t)N * 400 * 512);
+    tok = tok_;
+  }
   // split-K scratch of the 3x3 stride-1 layers for 1 .. 4 hypotheses: 4 shares x the largest fp32 output (256 channels at 40x40)
   float *sk = nullptr;
   if (N <= 4) {
@@ -392,6 +396,27 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
   // reshape(bs,C,-1).permute(0,2,1) is the NHWC tensor itself; pos_embed.pe added in the epilogue
   c = Conv2dCall{tC, N, 20, 20, &t[14]}; c.res = c1; c.out = tok; c.post_add = net->pe; c.post_period = 400;
   FP_TRY(run_conv(ctx, c, s, sk));
+  *tokens_out = tok;
+  return FP_OK;
+}
+
+// The trunk of a batch as TWO half batches on two streams (from 64 hypotheses on; FP_TRUNK_STREAMS=1: one).  The halves are
+// independent (nothing in the trunk couples hypotheses) and every 3x3 launch fills the chip alone - one workgroup per CU - so two
+// streams do not run side by side: what they buy is the LAST ROUND of each launch.  At 252 hypotheses a launch is 788 or 1575 tiles on
+// 256 CUs, 3.08 or 6.15 rounds, and the partial last round costs 3 - 8 % of it (as quarter tiles, round 1); with two half-batch launches
+// queued on two streams the workgroups of the other half start on the CUs the last round leaves idle.  Results are those of the single
+// batch bit for bit (a hypothesis' arithmetic does not depend on its batch).
+int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0, int NT, int N, f16 **tokens_out, hipStream_t s) {
+  static const int n_streams = getenv("FP_TRUNK_STREAMS") ? atoi(getenv("FP_TRUNK_STREAMS")) : 2;
+  const size_t img = (size_t)160 * 160 * 8;
+  if (n_streams < 2 || N < 64) return run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, tokens_out, s);
+  TAKE(tok, f16, (size_t)N * 400 * 512);
+  const int Na = N / 2;
+  StreamFanout fo(ctx, s, 2);
+  f16 *t = nullptr;
+  FP_TRY(run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, Na, &t, s, tok));
+  FP_TRY(run_trunk(ctx, net, in + (s0 + Na) * img, in + ((size_t)NT + s0 + Na) * img, N - Na, &t, fo.stream_for(0), tok + (size_t)Na * 400 * 512));
+  FP_TRY(fo.join());
   *tokens_out = tok;
   return FP_OK;
 }
@@ -431,11 +456,10 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
   const int CH = fp_hyp_chunk(NT);
   FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(CH)));
   const size_t mark = ctx->arena.off;
-  const size_t img = (size_t)160 * 160 * 8;
   auto body = [&](int s0, int N) -> int {
     f16 *tok = nullptr;
     const f16 *in = (const f16 *)d_net_in;
-    FP_TRY(run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, &tok, s));
+    FP_TRY(run_trunk_maybe_split(ctx, net, in, s0, NT, N, &tok, s));
     const int M = N * 400;
     // The translation and rotation heads are independent transformer layers on the same tokens: each gets its own
     // buffers and its own stream, so the tail of one head's kernels overlaps the other's (their launches are 3.08 rounds of
@@ -588,11 +612,10 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
   const int CH = fp_hyp_chunk(NT);
   FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(CH)));
   const size_t mark = ctx->arena.off;
-  const size_t img = (size_t)160 * 160 * 8;
   auto body = [&](int s0, int N) -> int {
     f16 *tok = nullptr;
     const f16 *in = (const f16 *)d_net_in;
-    FP_TRY(run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, &tok, s));
+    FP_TRY(run_trunk_maybe_split(ctx, net, in, s0, NT, N, &tok, s));
     const int M = N * 400;
     TAKE(qk, f16, (size_t)M * 1024);
     TAKE(vt, f16, (size_t)N * 4 * 128 * 416);

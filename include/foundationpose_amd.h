@@ -234,6 +234,9 @@ int fp_cluster_poses(float angle_diff_deg, float dist_diff_m, const float *h_pos
  * dominant class only (the 3x3 stride-1 convolutions: what a timed benchmark run carries); 2: around every class. */
 int fp_prof_enable(fp_ctx *ctx, int on);
 int fp_prof_read(fp_ctx *ctx, const char *kernel_class, double *total_ms, int64_t *launches, double *flops);
+/* time during which at least one launch of the class was executing (union of the launch spans; = total_ms unless launches of the
+ * class overlap on two streams): FLOPs / busy time is the rate the chip sustains on the class */
+int fp_prof_read_busy(fp_ctx *ctx, const char *kernel_class, double *busy_ms);
 int fp_prof_reset(fp_ctx *ctx);
 
 #ifdef __cplusplus

@@ -1,0 +1,31 @@
+"""Per kernel of a rocprofv3 --kernel-trace directory: calls, mean span of a dispatch, BUSY time (union of the dispatch intervals: the
+time during which at least one dispatch of the kernel was executing) and the mean number of its dispatches in flight.  Kernels whose
+launches overlap on two streams (the two half-batch trunks, the two RefineNet heads) have spans about twice their busy time per launch;
+FLOPs / busy time is the rate the chip sustains on the kernel.
+  python scripts/kernel_busy.py gpurun_out/prof_bench [out.json]"""
+import collections, csv, glob, json, sys
+f = glob.glob(sys.argv[1] + '/**/*_kernel_trace.csv', recursive=True)[0]
+iv = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+  iv[r['Kernel_Name']].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+rows = []
+for name, v in iv.items():
+  v.sort()
+  busy, a, b = 0, None, None
+  for s, e in v:
+    if a is None or s > b:
+      if a is not None:
+        busy += b - a
+      a, b = s, e
+    else:
+      b = max(b, e)
+  busy += b - a
+  span = sum(e - s for s, e in v)
+  rows.append(dict(kernel=name.split('(')[0][:100], calls=len(v), mean_span_us=span / len(v) / 1e3, busy_ms=busy / 1e6, busy_us_per_call=busy / len(v) / 1e3,
+                   in_flight=span / busy))
+rows.sort(key=lambda r: -r['busy_ms'])
+for r in rows[:30]:
+  print('%-90s calls %5d  span %8.1f us  busy/call %8.1f us  busy %8.2f ms  in flight %.2f' % (r['kernel'][:90], r['calls'], r['mean_span_us'], r['busy_us_per_call'],
+                                                                                                  r['busy_ms'], r['in_flight']))
+if len(sys.argv) > 2:
+  json.dump(rows, open(sys.argv[2], 'w'), indent=1)
