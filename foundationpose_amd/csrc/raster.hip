@@ -167,7 +167,8 @@ __device__ void clip_matrix(const RenderArgs &a, int b, const float *pose, float
 
 // Vertex pre-pass: every hypothesis' vertices ONCE.
 //   C (int4):   X (INT_MIN = behind the camera / off range), Y, bits of z/w, bits of w - exactly xform_vertex's values;
-//   A (uint2):  X | Y << 16 as int16 where |X|, |Y| < 16384 (the range of the 32-bit edge functions), else RB_A_NONE; bits of z/w;
+//   A (uint2):  X | Y << 16 as int16 where |X|, |Y| < 16384 (the range of the 32-bit edge functions) and bits of z/w; else RB_A_NONE
+//               and bits of w;
 //   B (2 x float4): camera-space position (pts_cam, src/Utils.py:168) and the vertex' Lambert term (src/Utils.py:200-206) - the
 //               expressions the per-pixel resolve evaluated until round 3, moved here verbatim -, then colour and w.
 #define RB_A_NONE 0x7fff7fffu
@@ -215,7 +216,9 @@ __global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 
   const size_t r = (size_t)b * m.V + v;
   recC[r] = make_int4(o.ok ? o.X : (int)0x80000000, o.Y, __float_as_int(o.zn), __float_as_int(o.w));
   const bool small = o.ok && abs(o.X) < 16384 && abs(o.Y) < 16384;
-  recA[r] = make_uint2(small ? ((unsigned)o.X & 0xffffu) | ((unsigned)o.Y << 16) : RB_A_NONE, __float_as_uint(o.zn));
+  // (where A cannot describe the vertex its second word carries w instead of z/w: the classification drops faces whose three
+  // vertices are all on or behind the camera plane - a drifted tracking pose puts the whole mesh there - without reading C)
+  recA[r] = small ? make_uint2(((unsigned)o.X & 0xffffu) | ((unsigned)o.Y << 16), __float_as_uint(o.zn)) : make_uint2(RB_A_NONE, __float_as_uint(o.w));
   recB[2 * r] = make_float4(pc[0], pc[1], pc[2], dv);
   float4 cw = make_float4(0.f, 0.f, 0.f, o.w);
   if (m.vcolor) cw.x = m.vcolor[v * 3], cw.y = m.vcolor[v * 3 + 1], cw.z = m.vcolor[v * 3 + 2];
@@ -256,7 +259,11 @@ __global__ __launch_bounds__(RB_THREADS) void classify_faces_kernel(RenderArgs a
     if (t + RB_THREADS < f1) f_n = m.faces4[t + RB_THREADS];
     const uint2 a0 = getA(f.x), a1 = getA(f.y), a2 = getA(f.z);
     if (a0.x == RB_A_NONE || a1.x == RB_A_NONE || a2.x == RB_A_NONE) {
-      // cannot be bounded here: every strip looks at it (faces entirely behind the camera are dropped there)
+      // a vertex A cannot describe.  Entirely on or behind the camera plane (w <= 0 for all three; a describable vertex has w > 0):
+      // dropped, as the triangle pass would.  Otherwise the face cannot be bounded here: every strip looks at it.
+      const bool front = (a0.x != RB_A_NONE || __uint_as_float(a0.y) > 0.f) || (a1.x != RB_A_NONE || __uint_as_float(a1.y) > 0.f) ||
+                         (a2.x != RB_A_NONE || __uint_as_float(a2.y) > 0.f);
+      if (!front) continue;
       for (int sI = 0; sI < S; ++sI) lB[(size_t)sI * seg + atomicAdd(&cs[sI][2], 1)] = (unsigned)t | RB_SLOW;
       continue;
     }

@@ -8,5 +8,5 @@ import bench
 
 dev = torch.device('cuda', 0)
 est, _ = bench.build_job(dev, n_objects=1, rank=0)
-est.refiner.ctx.reserve(64)
+est.refiner.ctx.reserve(int(os.environ.get('RESERVE', '64')))
 print(json.dumps(bench.tracking_fps(est, dev, n_frames=int(os.environ.get('FRAMES', '200'))), indent=1))
