@@ -411,11 +411,14 @@ int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0,
   const size_t img = (size_t)160 * 160 * 8;
   if (n_streams < 2 || N < 64) return run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, tokens_out, s);
   TAKE(tok, f16, (size_t)N * 400 * 512);
-  const int Na = N / 2;
-  StreamFanout fo(ctx, s, 2);
+  const int n_parts = std::min(n_streams, std::min(fp_ctx::NSIDE, N / 32));
+  StreamFanout fo(ctx, s, n_parts);
   f16 *t = nullptr;
-  FP_TRY(run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, Na, &t, s, tok));
-  FP_TRY(run_trunk(ctx, net, in + (s0 + Na) * img, in + ((size_t)NT + s0 + Na) * img, N - Na, &t, fo.stream_for(0), tok + (size_t)Na * 400 * 512));
+  for (int k = 0, a0 = 0; k < n_parts; ++k) {
+    const int a1 = (int)((long long)N * (k + 1) / n_parts);
+    FP_TRY(run_trunk(ctx, net, in + (s0 + a0) * img, in + ((size_t)NT + s0 + a0) * img, a1 - a0, &t, k == 0 ? s : fo.stream_for(k - 1), tok + (size_t)a0 * 400 * 512));
+    a0 = a1;
+  }
   FP_TRY(fo.join());
   *tokens_out = tok;
   return FP_OK;
