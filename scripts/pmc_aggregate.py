@@ -73,8 +73,13 @@ def main():
           + 4 * (2 * X) + 2 * X      # C=256
           + 4 * X + X                # C=512 (tensors are X/2)
           + 4 * 9 * (128 * 128 + 256 * 256 + 512 * 512) * 2.0) / 12
-  js = {'per': 'launch (mean over the stride-1 3x3 convolutions of one bench step, N=252)', 'unit': 'bytes', 'fetch': fe, 'write': wr,
-        'total': fe + wr, 'algorithmic': algo, 'launches_profiled': n,
+  # `algo` is per FULL-BATCH launch (72 per step); since round 3 the trunk runs as two half batches (144 launches per step, half the
+  # bytes each, the weights read twice): scale by the launches actually profiled
+  steps = sum(r[2] for r in rows if 'render_kernel<1' in r[0]) / 6.0
+  per_step = n / steps if steps else 72.0
+  algo = (algo - 4 * 9 * (128 * 128 + 256 * 256 + 512 * 512) * 2.0 / 12) * 72.0 / per_step + 4 * 9 * (128 * 128 + 256 * 256 + 512 * 512) * 2.0 / 12
+  js = {'per': 'launch (mean over the stride-1 3x3 convolutions of one bench step, N=252; %.0f launches per step)' % per_step, 'unit': 'bytes', 'fetch': fe, 'write': wr,
+        'total': fe + wr, 'algorithmic': algo, 'launches_profiled': n, 'launches_per_step': per_step,
         'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py (scripts/pmc_traffic.sh, '
                   'profiles/' + ROUND + '_pmc_hbm_traffic.csv); FETCH_SIZE doubled (gfx950 counts 128-B requests of 16-B/lane streams as 64 B), '
                   'WRITE_SIZE as is; Infinity-Cache hits are included in FETCH_SIZE, so this is fabric (L2-miss) traffic, an upper '
