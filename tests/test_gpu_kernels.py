@@ -617,3 +617,29 @@ def test_head_mlp_vs_fp32_reference(fp, n_hyp):
   d = float((gs_d - got).abs().max())
   print(f'head_mlp M={M}: max |fused - three launches| = {d:.2e}')
   assert d <= 2.5e-3 * float(ref.abs().max()) + 1e-3
+
+
+def test_profiling_busy_time_is_the_union_of_launch_spans(fp):
+  """fp_prof_read / fp_prof_read_busy (bench.py's roofline figure): per kernel class the sum of the launch spans and the time with at
+  least one launch executing.  A RefineNet pass on 8 hypotheses: the convolutions follow one another on one stream (busy == sum of
+  spans); the two heads run on two streams, so the `linear` class must report busy <= sum of spans, and both > 0."""
+  from foundationpose_amd import _lib, synthetic as S
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  ctx = fp['ctx']
+  net = _lib.DeviceNet(ctx, _lib.FP_NET_REFINE, S.make_refine_state_dict(0), True)
+  x = (torch.rand((16, 160, 160, 8), device='cuda') - 0.5).half()
+  trans, rot = torch.empty((8, 3), device='cuda'), torch.empty((8, 3), device='cuda')
+  run = lambda: check(lib().fp_refine_forward(ctx.handle, net.handle, ptr(x), 8, ptr(trans), ptr(rot), stream_ptr()))
+  run()
+  torch.cuda.synchronize()
+  ctx.prof_reset()
+  ctx.prof_enable(2)
+  for _ in range(3):
+    run()
+  torch.cuda.synchronize()
+  ctx.prof_enable(False)
+  conv, lin = ctx.prof_read('conv3x3_halo'), ctx.prof_read('linear')
+  ctx.prof_reset()
+  assert conv['launches'] == 3 * 12 and lin['launches'] == 3 * 4
+  assert conv['busy_ms'] > 0 and abs(conv['busy_ms'] - conv['total_ms']) <= 0.02 * conv['total_ms'] + 0.01
+  assert 0 < lin['busy_ms'] <= lin['total_ms'] * 1.001 + 0.001
