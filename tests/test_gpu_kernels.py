@@ -643,3 +643,22 @@ def test_profiling_busy_time_is_the_union_of_launch_spans(fp):
   assert conv['launches'] == 3 * 12 and lin['launches'] == 3 * 4
   assert conv['busy_ms'] > 0 and abs(conv['busy_ms'] - conv['total_ms']) <= 0.02 * conv['total_ms'] + 0.01
   assert 0 < lin['busy_ms'] <= lin['total_ms'] * 1.001 + 0.001
+
+
+def test_render_mesh_too_large_for_lds_and_wide_output(fp):
+  """Rasteriser paths the 8k-vertex bench mesh does not take: (a) a mesh of more than 8192 vertices, whose A records do not fit
+  beside the strip in LDS (the triangle pass gathers them from global memory instead); (b) an output wider than a crop (320 x 240: the
+  strip count follows the LDS budget).  Both against the oracle, same tolerance as test_render_crops_match_oracle."""
+  from oracle import geometry as G
+  s = util.scene(0, n_theta=128, n_z=110)
+  assert s['mt']['pos'].shape[0] > 8192
+  poses = util.hypotheses(s, 5, jitter_seed=9)
+  tf = G.compute_crop_window_tf_batch(torch.from_numpy(poses), s['K'], 1.2, (160, 160), s['diameter'])
+  bbox = G.crop_bbox2d_ori(tf, (160, 160))
+  for out, bb in (((160, 160), bbox), ((240, 320), None)):
+    ref, got = _render_pair(s, fp, poses if bb is not None else poses[:2], bb if bb is not None else None, out, mt_cpu=s['mt'])
+    cov_o, cov_g = ref[1] > 0, got[1] > 0
+    assert float((cov_o != cov_g).float().mean()) <= 1e-4 and float(cov_o.float().mean()) > 0.005
+    for name, a, b in zip(('color', 'depth', 'normal', 'xyz'), ref, got):
+      frac, mx, med = util.mismatch_report(a.numpy(), b.numpy(), 2e-6)
+      assert frac <= 2e-4, f'{out} {name}: {frac:.2e} of values differ by > 2e-6 (max {mx:.2e})'
