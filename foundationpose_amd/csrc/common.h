@@ -217,8 +217,11 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 bool s2_supported(const ConvArgs &a);
 int s2_ct_for(int Cout);
 size_t s2_packed_halfs(int Cout, int Cin);
-int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s);
+int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s, int ct_force = 0);   // ct_force: co tiles of 32 per wave group (0: s2_ct_for)
 int launch_conv_s2(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
+// conv_s1b.hip: band-in-LDS form of the 128 -> 128 stride-1 layers on 40x40 maps (experiment, FP_C128_BAND=1)
+bool s1b_supported(const ConvArgs &a);
+int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
 // Column of token t inside the transposed V image [b][4][128][416].  Within each group of 16 tokens the order is
 // {0-3, 8-11, 4-7, 12-15}: the 8 keys that one lane half of the attention kernel's P^T operand carries (the S^T

@@ -468,6 +468,10 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const bool halo = conv_halo_supported(a);
   const char *cls = halo ? "conv3x3_halo" : (a.KW == 3) ? "conv3x3_s2" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
+  {
+    static const bool band128 = !(getenv("FP_C128_BAND") && atoi(getenv("FP_C128_BAND")) == 0);   // conv_s1b.hip; FP_C128_BAND=0: the halo kernel (A/B timing knob)
+    if (band128 && a.Nimg >= 16 && s1b_supported(a)) return launch_conv_s1b(ctx, a, s);
+  }
   if (halo) return launch_conv_halo(a, s);
   if (stem_supported(a)) return launch_stem(ctx, a, s);
   if (a.wpk && a.M >= S2_MIN_PIXELS && s2_supported(a)) return launch_conv_s2(ctx, a, s);

@@ -1,0 +1,211 @@
+// 3x3 / stride-1 / pad-1 convolution 128 -> 128 on 40x40 maps (the four ResnetBasicBlock convolutions of encodeA / encoderA,
+// network_modules.py:73-111 via refine_network.py:39-40) on the structure of conv_s2.hip instead of conv_halo.hip (round 3; batches of
+// >= 8 hypotheses; FP_C128_BAND=0 selects the halo kernel for an A/B).  Measured on full-batch launches (504 images, kernel trace):
+// 215 / 242 us without / with residual against 223 / 247 us for conv3x3_halo_dma_kernel<40> - 1106 / 983 against 1067 / 965 TFLOP/s.
+//
+// With four K chunks of 32 channels the 8-wave halo kernel spends 39 % of a workgroup's life in prologue and epilogue, one workgroup
+// per CU.  Here
+//   * a workgroup (4 waves) owns 8 output rows x 40 = 320 pixels of ONE image (5 tiles per image: no tile straddles two) x all 128
+//     output channels: wave (c, p) owns 64 couts (2 accumulator tiles) x the 160 pixels of rows 4p .. 4p+3 (5 pixel tiles of 32);
+//   * per 16-channel chunk the band (10 input rows x 42 columns of 32-byte pixels, row pitch 56 slots: 56 = 40 (mod 16) keeps the lane ->
+//     bank map of a 32-pixel tile unchanged across its row breaks; the two 16-byte halves of slot q swapped when bit 3 of q is set) goes
+//     to LDS once by LDS-DMA, double buffered, and feeds all 9 taps;
+//   * weights never touch LDS: packed at load time in MFMA-fragment order (s2_pack_weights), each wave streams the fragments of its 64
+//     couts L2 -> registers three taps ahead: 2 KB per 10 MFMAs;
+//   * two workgroups per CU (40 KB LDS, <= 256 VGPRs each).
+// Epilogue: accumulators start at the folded BN bias; residual rows staged through LDS and added in fp32, ReLU, one rounding to fp16,
+// 16-byte NHWC stores (with the channel-concat addressing of the last encodeA layer: out_ld / split_m / coff_hi).
+#include "common.h"
+
+#define B1_THREADS 256
+#define B1_W 40
+#define B1_ROWS 8
+#define B1_P 56
+#define B1_BROWS (B1_ROWS + 2)
+#define B1_BAND_INSTR 20                                  // 1-KB DMA instructions per chunk: 560 slots of 32 B = 17.5 KB, 5 per wave
+#define B1_BAND_BYTES (B1_BAND_INSTR * 1024)
+#define B1_DPW (B1_BAND_INSTR / 4)
+#define B1_NPT 5
+#define B1_STAGE_LD 72                                    // halfs per staged pixel: 64 couts + 8 pad
+#define B1_LDS_BYTES (2 * B1_BAND_BYTES)
+
+__device__ __forceinline__ void b1_glds16(const void *g, unsigned lds_addr) {
+  lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+
+template <bool RES>
+__global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs p, const f16 *__restrict__ wpk, const f16 *__restrict__ zero_page, int n_tiles) {
+  constexpr int W = B1_W, H = B1_W, P = B1_P, NPT = B1_NPT, DPW = B1_DPW, CT = 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char b1_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ch = wave & 1, ph = wave >> 1;                 // cout half, pixel half
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)b1_smem;
+  const int tile = xcd_remap(blockIdx.x, n_tiles);
+  const int img = tile / (H / B1_ROWS), oy0 = (tile - img * (H / B1_ROWS)) * B1_ROWS;
+  const int nch = p.Cin >> 4;
+
+  // ---- band DMA: instruction u = wave + 4 v, lane l -> slot q = 32 u + l/2, physical half l&1 = logical half ^ bit 3 of q ----
+  unsigned src_off[DPW];                                   // byte offset of (pixel, logical half) in the input, chunk 0; ~0u: zeros
+#pragma unroll
+  for (int v = 0; v < DPW; ++v) {
+    const int q = (wave + 4 * v) * 32 + (lane >> 1), hl = (lane & 1) ^ ((q >> 3) & 1);
+    const int b = q / P, c = q - b * P;
+    const int iy = oy0 - 1 + b, ix = c - 1;
+    const bool ok = b < B1_BROWS && c < W + 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    src_off[v] = ok ? (unsigned)((((img * H + iy) * W + ix) * p.Cin + hl * 8) * 2) : 0xffffffffu;
+  }
+  auto band_dma = [&](int chunk, int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int v = 0; v < DPW; ++v) {
+      const char *src = src_off[v] != 0xffffffffu ? (const char *)p.in + src_off[v] + chunk * 32 : (const char *)zero_page;
+      b1_glds16(src, lds0 + buf * B1_BAND_BYTES + (wave + 4 * v) * 1024);
+    }
+  };
+  // ---- B fragments: lane = output pixel 32 j + lr of the wave's 160 (local row jr of its 4, column ox), k half lh; tap (ky, kx) of
+  // that pixel is slot qb[j] + ky P + kx (band row 4 ph + jr + ky holds input row oy0 + 4 ph + jr + ky - 1, slot c holds column c - 1)
+  int qb[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int pl = 32 * j + lr, jr = pl / W, ox = pl - jr * W;
+    qb[j] = (((4 * ph + jr) * P + ox) << 5) | (lh << 4);
+  }
+  // ---- A fragments: this wave's stream of 1-KB fragments, (chunk, tap, co tile) in order (s2_pack_weights, group = cout half) ----
+  const half8 *wp = reinterpret_cast<const half8 *>(wpk) + ((size_t)ch * nch * 9 * CT) * 64 + lane;
+  half8 aq[3][CT];
+  int f = 0;
+  auto a_fetch = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) aq[slot][ct] = wp[(size_t)(f * CT + ct) * 64];
+    ++f;
+  };
+  band_dma(0, 0);
+#pragma unroll
+  for (int d = 0; d < 3; ++d) a_fetch(d);
+
+  floatx16 acc[CT][NPT];
+  {
+    const int co0 = ch * 64;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + co0 + ct * 32 + rg * 8 + lh * 4);
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+          acc[ct][j][rg * 4 + 0] = bv.x;
+          acc[ct][j][rg * 4 + 1] = bv.y;
+          acc[ct][j][rg * 4 + 2] = bv.z;
+          acc[ct][j][rg * 4 + 3] = bv.w;
+        }
+      }
+  }
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (chunk + 1 < nch) band_dma(chunk + 1, (chunk + 1) & 1);
+    const unsigned char *band = b1_smem + (chunk & 1) * B1_BAND_BYTES;
+    auto b_read = [&](int t, int j) __attribute__((always_inline)) -> half8 {
+      const int ky = t / 3, kx = t - ky * 3;
+      int x = qb[j];
+      asm volatile("" : "+v"(x));
+      x += (ky * P + kx) << 5;
+      return *reinterpret_cast<const half8 *>(band + (x ^ ((x >> 4) & 16)));
+    };
+    half8 b[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) b[j] = b_read(0, j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[t % 3][ct], b[j], acc[ct][j], 0, 0, 0);
+        if (t < 8) b[j] = b_read(t + 1, j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      a_fetch(t % 3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: one 32-pixel tile at a time through this wave's staging rows (32 px x 64 couts) ----
+  f16 *stage = reinterpret_cast<f16 *>(b1_smem) + (size_t)wave * (32 * B1_STAGE_LD);
+  const float lo = p.relu ? 0.f : -__builtin_inff();
+  const int m_wave = (img * H + oy0 + 4 * ph) * W;        // first output pixel of this wave (flattened over images)
+  const int co0 = ch * 64;
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    if constexpr (RES) {
+      // residual rows of the tile: 16-byte pieces, 8 lanes per pixel row of 64 couts -> staging, then added in fp32 in the accumulator layout
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int px = u * 8 + (lane >> 3), c8 = lane & 7;
+        const int m = m_wave + 32 * j + px;
+        const uint4 rv = *reinterpret_cast<const uint4 *>(p.res + (size_t)m * p.Cout + co0 + c8 * 8);
+        *reinterpret_cast<uint4 *>(&stage[px * B1_STAGE_LD + c8 * 8]) = rv;
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        f16 *sp = &stage[lr * B1_STAGE_LD + ct * 32 + rg * 8 + lh * 4];
+        float v[4] = {acc[ct][j][rg * 4 + 0], acc[ct][j][rg * 4 + 1], acc[ct][j][rg * 4 + 2], acc[ct][j][rg * 4 + 3]};
+        if constexpr (RES) {
+          const half4 rq = *reinterpret_cast<const half4 *>(sp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rq[e];
+        }
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = (f16)fmaxf(v[e], lo);
+        *reinterpret_cast<half4 *>(sp) = hv;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    uint4 v4[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v4[u] = *reinterpret_cast<const uint4 *>(&stage[(u * 8 + (lane >> 3)) * B1_STAGE_LD + (lane & 7) * 8]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m_wave + 32 * j + u * 8 + (lane >> 3);
+      const bool hi = m >= p.split_m;
+      const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+      *reinterpret_cast<uint4 *>((f16 *)p.out + orow * p.out_ld + (hi ? p.coff_hi : 0) + co0 + (lane & 7) * 8) = v4[u];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+bool s1b_supported(const ConvArgs &a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.out_mode == 0 && !a.post_add && a.H == B1_W && a.W == B1_W && a.Cin == 128 &&
+         a.Cout == 128 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0 && a.wpk != nullptr && !(a.splitk && a.ksplit > 1);
+}
+
+int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
+  FP_REQUIRE(s1b_supported(a), "launch_conv_s1b: unsupported layer");
+  static bool set0 = false, set1 = false;
+  const int n_tiles = a.Nimg * (B1_W / B1_ROWS);
+  if (a.res) {
+    if (!set1) {
+      FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_s1_band_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES));
+      set1 = true;
+    }
+    hipLaunchKernelGGL(conv3x3_s1_band_kernel<true>, dim3(n_tiles), dim3(B1_THREADS), B1_LDS_BYTES, s, a, a.wpk, (const f16 *)ctx->zero_page, n_tiles);
+  } else {
+    if (!set0) {
+      FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_s1_band_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES));
+      set0 = true;
+    }
+    hipLaunchKernelGGL(conv3x3_s1_band_kernel<false>, dim3(n_tiles), dim3(B1_THREADS), B1_LDS_BYTES, s, a, a.wpk, (const f16 *)ctx->zero_page, n_tiles);
+  }
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}

@@ -227,8 +227,8 @@ bool s2_supported(const ConvArgs &a) {
 
 size_t s2_packed_halfs(int Cout, int Cin) { return (size_t)Cout * 9 * Cin + 3 * 2 * 512; }    // + three taps of prefetch past the end
 
-int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s) {
-  const int ct = s2_ct_for(Cout);
+int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s, int ct_force) {
+  const int ct = ct_force ? ct_force : s2_ct_for(Cout);
   FP_REQUIRE(ct != 0 && Cin % 16 == 0 && Kpad >= 9 * Cin, "s2_pack_weights: unsupported layer");
   const size_t total = (size_t)Cout * 9 * Cin;
   FP_CHECK_HIP(hipMemsetAsync(d_out + total, 0, (s2_packed_halfs(Cout, Cin) - total) * sizeof(f16), s));
