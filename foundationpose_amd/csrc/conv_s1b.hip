@@ -1,7 +1,11 @@
 // 3x3 / stride-1 / pad-1 convolution 128 -> 128 on 40x40 maps (the four ResnetBasicBlock convolutions of encodeA / encoderA,
-// network_modules.py:73-111 via refine_network.py:39-40) on the structure of conv_s2.hip instead of conv_halo.hip (round 3; batches of
-// >= 8 hypotheses; FP_C128_BAND=0 selects the halo kernel for an A/B).  Measured on full-batch launches (504 images, kernel trace):
-// 215 / 242 us without / with residual against 223 / 247 us for conv3x3_halo_dma_kernel<40> - 1106 / 983 against 1067 / 965 TFLOP/s.
+// network_modules.py:73-111 via refine_network.py:39-40) on the structure of conv_s2.hip instead of conv_halo.hip: the measured
+// alternative of round 3, selected by FP_C128_BAND=1 for batches of >= 8 hypotheses, OFF by default.  On full-batch
+// launches (504 images, kernel trace): 215 / 242 us without / with residual against 223 / 247 us for conv3x3_halo_dma_kernel<40> -
+// 1106 / 983 against 1067 / 965 TFLOP/s, 0.1 ms of a 36.5-ms step.  Not the default because a different accumulation order (16-channel
+// chunks, taps inside) moves the fp16 noise of the scorer's logits: on one of the twelve full-size fixtures (c3L_3, the smallest
+// top-1 / top-2 margin) the margin falls from 20+ to 15 x that noise - identical argmax, but the fixture's margin rule was set on the
+// halo kernel, and 0.1 ms does not buy re-tuning a parity fixture.
 //
 // With four K chunks of 32 channels the 8-wave halo kernel spends 39 % of a workgroup's life in prologue and epilogue, one workgroup
 // per CU.  Here
