@@ -179,6 +179,47 @@ def test_full_gain_chain_on_hypotheses_whose_windows_never_flip(name, full, pred
   assert e[-1] < 5 * POSE_TOL, f'{name}: worst never-flipped hypothesis after 5 full-gain iterations'
 
 
+def test_argmax_over_tail_seeds_nobody_selected(full, predictors):
+  """the fixtures' ScoreNet tail (att_cross + linear) was drawn from a seed chosen to make the top-1 / top-2 margin
+  comfortable.  Here the tail is drawn from 24 seeds nobody looked at: the oracle's logits (float64 tail on the oracle's fp32 features of the
+  c1 fixture, 252 hypotheses) against the HIP tail on the HIP features of the same poses.  A near-tie cannot be decided by any fp16
+  implementation, so the rule is conditional and the counts are printed: whenever the oracle's margin is at least 5 x the measured
+  differential logit noise of that seed the argmax must be identical - and that must be the case for most seeds, or the rule tests nothing."""
+  from foundationpose_amd import _lib, synthetic as S
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  from oracle import nets
+  _, _, scorer = predictors
+  c = cases.case('c1')
+  sc = c['sc']
+  mt = util.to_dev(sc['mt'])
+  poses = full['c1/poses_iter'][-1]
+  feats_gpu = scorer.extract_features(sc['rgb'], c['depth'], sc['K'], poses, mesh_tensors=mt, mesh_diameter=sc['diameter'])
+  feats_ora = torch.as_tensor(full['c1/feats']).double()
+  base = S.make_score_state_dict(cases.SCORE_SEED)
+  decided = same = 0
+  ratios = []
+  for seed in range(5000, 5024):
+    tail = S.make_score_state_dict(cases.SCORE_SEED, tail_seed=seed, tail_only=True)
+    sd64 = {k: v.double() for k, v in tail.items()}
+    want = nets.score_tail(sd64, feats_ora, len(feats_ora)).reshape(-1).numpy()
+    net = _lib.DeviceNet(scorer.ctx, _lib.FP_NET_SCORE, dict(base, **tail), use_bn=True)
+    logits = torch.empty((1, len(poses)), device='cuda')
+    am = torch.empty((1,), dtype=torch.int32, device='cuda')
+    check(lib().fp_score_tail(scorer.ctx.handle, net.handle, ptr(feats_gpu), 1, len(poses), ptr(logits), ptr(am), stream_ptr()))
+    got = logits.reshape(-1).double().cpu().numpy()
+    noise = float(np.abs((got - got.mean()) - (want - want.mean())).max())
+    o = np.sort(want)[::-1]
+    margin = float(o[0] - o[1])
+    ratios.append(margin / max(noise, 1e-12))
+    if margin >= 5 * noise:
+      decided += 1
+      assert int(got.argmax()) == int(want.argmax()) == int(am[0]), f'tail seed {seed}: margin {margin:.2e}, noise {noise:.2e}'
+    same += int(got.argmax()) == int(want.argmax())
+  print(f'24 unselected tail seeds: oracle margin / logit noise min {min(ratios):.1f}, median {np.median(ratios):.1f}; {decided} decided (>= 5 x noise), '
+        f'identical argmax on {same} of 24')
+  assert decided >= 16
+
+
 def test_c1_features_follow_the_oracle(full, predictors):
   """ScoreNet features (252 x 512) on the ORACLE's refined poses against the oracle's fp32 features: the input-dependent part
   (feature minus its mean over the hypotheses) to 10 % of its spread."""
