@@ -280,12 +280,32 @@ extern "C" int fp_crop_window_tf(fp_ctx *ctx, const float *d_poses, int N, const
 // from the context's arena and is released when the launches are queued - the next taker runs behind them on the same stream.
 static int render_with_arena_scratch(fp_ctx *ctx, RenderArgs &a, hipStream_t s) {
   if (a.N <= 0) return launch_render(ctx, a, s);
-  const RenderPlan pl = render_plan(a.N, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
+  // The face lists are sized for the worst case (every face in every strip): a large batch at a large output size (many strips) is
+  // rendered in sub-batches so that the scratch stays below 1 GiB (a sub-batch's launches run behind the previous one's: one scratch).
+  const int N = a.N;
+  int chunk = N;
+  static const size_t cap = getenv("FP_RENDER_SCRATCH_MAX") ? (size_t)atoll(getenv("FP_RENDER_SCRATCH_MAX")) : ((size_t)1 << 30);      // (tests lower it)
+  while (chunk > 1 && render_plan(chunk, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu).total > cap) chunk = (chunk + 1) / 2;
+  const RenderPlan pl = render_plan(chunk, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
   FP_TRY(fp_arena_ensure(ctx, pl.total + 4096));
   const size_t mark = ctx->arena.off;
-  a.scratch = ctx->arena.take(pl.total);
-  a.scratch_bytes = pl.total;
-  const int rc = a.scratch ? launch_render(ctx, a, s) : FP_ENOMEM;
+  void *scratch = ctx->arena.take(pl.total);
+  int rc = scratch ? FP_OK : FP_ENOMEM;
+  const size_t px = (size_t)a.Ho * a.Wo;
+  for (int b0 = 0; b0 < N && rc == FP_OK; b0 += chunk) {
+    RenderArgs c = a;
+    c.N = std::min(chunk, N - b0);
+    c.poses = a.poses + (size_t)b0 * 16;
+    if (a.bbox2d) c.bbox2d = a.bbox2d + (size_t)b0 * 4;
+    if (a.color) c.color = a.color + b0 * px * 3;
+    if (a.depth) c.depth = a.depth + b0 * px;
+    if (a.normal) c.normal = a.normal + b0 * px * 3;
+    if (a.xyz) c.xyz = a.xyz + b0 * px * 3;
+    if (a.net_out) c.net_out = a.net_out + b0 * px * 8;
+    c.scratch = scratch;
+    c.scratch_bytes = pl.total;       // (a smaller last sub-batch needs no more than a full one)
+    rc = launch_render(ctx, c, s);
+  }
   ctx->arena.off = mark;
   return rc;
 }

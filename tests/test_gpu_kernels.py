@@ -662,3 +662,20 @@ def test_render_mesh_too_large_for_lds_and_wide_output(fp):
     for name, a, b in zip(('color', 'depth', 'normal', 'xyz'), ref, got):
       frac, mx, med = util.mismatch_report(a.numpy(), b.numpy(), 2e-6)
       assert frac <= 2e-4, f'{out} {name}: {frac:.2e} of values differ by > 2e-6 (max {mx:.2e})'
+
+
+def test_render_in_sub_batches(tmp_path):
+  """A standalone render whose worst-case scratch (face lists sized for every face in every strip) exceeds the limit is rendered in
+  sub-batches (api.hip: render_with_arena_scratch; 1 GiB by default - 220 full-frame poses).  With the limit lowered to 4 MB in a child
+  process (the knob is read once per process) 12 crops go out in sub-batches of one or two: bit-identical to the single launch."""
+  import os, subprocess, sys
+  script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'render_dump.py')
+  outs = []
+  for name, env in (('whole', {}), ('chunked', {'FP_RENDER_SCRATCH_MAX': '4000000'})):
+    path = str(tmp_path / (name + '.npz'))
+    r = subprocess.run([sys.executable, script, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    outs.append(np.load(path))
+  for k in ('c', 'd', 'n', 'x'):
+    assert np.array_equal(outs[0][k], outs[1][k]), k
+  assert float((outs[0]['d'] > 0).mean()) > 0.15
