@@ -11,16 +11,15 @@
 #define AT_TP 416    // padded token count of the transposed V image [b][4][128][416]
 #define AT_MAXT 400
 #define FA_WAVES 7
-#define FA_NSTAGE 4
-#define FA_AHEAD 2      // key blocks the DMA runs ahead: slot kb-1 must survive iteration kb for the staggered waves
-#ifndef FA_STAGGER
-#define FA_STAGGER 0    // 1: waves 4-6 run PV(k-1) at the start of iteration k (measured: same time, 208-214 us either way)
-#endif
+#define FA_NSTAGE 3
+#define FA_AHEAD 2      // key blocks the DMA runs ahead: block p + 2 goes to the ring slot of block p - 1 once every wave is past barrier p
 #define FA_DMA_PER_WAVE 5   // ceil(32 DMA instructions per stage / 7 waves); surplus slots repeat an earlier one
 #define FA_THREADS (FA_WAVES * 64)
 #define FA_QB (FA_WAVES * 32)   // queries per workgroup
 #define FA_KB 64                // keys per pipeline stage
 #define FA_STAGE_HALFS (FA_KB * AT_DH * 2)   // K block [64][128] + V^T block [128][64]
+#define FA_QW_HALFS (32 * AT_DH)             // a wave's Q^T staging area: 8 fragments x 64 lanes x 8 halfs (8 KB)
+#define FA_LDS_BYTES ((FA_NSTAGE * FA_STAGE_HALFS + FA_WAVES * FA_QW_HALFS) * 2)
 
 // LDS-DMA from inline asm (see conv_halo.hip: through the builtin, hipcc turns every later LDS-read wait into lgkmcnt(0));
 // completion is waited for by the explicit s_waitcnt vmcnt(n) in front of the barriers of the key loop.
@@ -30,11 +29,20 @@ __device__ __forceinline__ void at_glds16(const f16 *g, f16 *l) {
 }
 
 // Flash-style multi-head self-attention core (400 tokens, 4 heads x 128) on v_mfma_f32_32x32x16_f16.
-// One workgroup = one (hypothesis, head, 224-query block): 13 query tiles of 32 split 7 + 6 over two workgroups;
-// each of the 7 waves owns 32 queries and keeps Q^T (32 regs), the running max / sum and O^T (4 x 32x32
-// accumulators) in registers.  Keys stream through LDS in blocks of 64 (K block + V^T block = 32 KB) in a
-// 4-deep ring filled by LDS-DMA THREE blocks ahead: counted s_waitcnt vmcnt(N) + raw s_barrier keep the later
-// blocks in flight across the barrier (a __syncthreads() would drain them).  128 KB LDS, 1 workgroup per CU.
+// A work item = one (hypothesis, head, 224-query block): 13 query tiles of 32 split 7 + 6 over two items; each of the
+// 7 waves owns 32 queries and keeps Q^T (32 regs), the running max / sum and O^T (4 x 32x32 accumulators) in registers.
+// Keys stream through LDS in blocks of 64 (K block + V^T block = 32 KB) in a 3-deep ring filled by LDS-DMA TWO blocks
+// ahead: counted s_waitcnt vmcnt(N) + raw s_barrier keep the later blocks in flight across the barrier (a __syncthreads()
+// would drain them).
+// PERSISTENT workgroups (one per CU, 152 KB LDS): workgroup j walks the items j, j + grid, j + 2 grid, ... and the DMA ring
+// does not stop at an item boundary - the last two iterations of item i stage the first two key blocks of item i + 1, and the
+// Q^T fragments of item i + 1 come by LDS-DMA into a per-wave 8-KB area (in fragment order: lane-linear, one conflict-free
+// ds_read_b128 per fragment) right after the first S^T phase of item i has consumed its own.  As one item per workgroup a
+// workgroup spent 17 k of its 47 k cycles on a start-up nothing covered (stamps: Q 7.5 k, DMA issue 2.9 k, block-0 wait 6.8 k).
+// vmcnt accounting (loads, stores and LDS-DMA retire in issue order): per iteration a wave issues 5 DMA instructions (the
+// block two ahead), in iteration 0 of an item 8 more (the next item's Q^T) after its S^T phase, and 8 stores at the end of
+// an item (none if all 32 queries of the wave are past T); the wait in front of barrier p allows exactly the operations
+// younger than block p that need not have landed (see `allowed` below).
 //   S^T = K Q^T       : A = K rows from LDS (swizzled: chunk ^ (key&15), conflict-free b128), B = Q^T in registers;
 //                       the lane that owns query column q sees 16 of each 32 keys, its partner lane+32 the rest.
 //   online softmax     : per key block, max / sum finish with one xor-32 shuffle; exp((s-m)/sqrt(128)).
@@ -47,17 +55,19 @@ __device__ __forceinline__ void at_glds16(const f16 *g, f16 *l) {
 // exp2 with the scale folded into one packed fma per two scores, v_max3, packed adds, tail masking only in the last key
 // block, O^T rescaled only when some lane's running max moved, LDS fragment offsets and DMA gather offsets precomputed
 // per lane (the DMA of a slot is scalar base + min(key, limit) * stride + lane constant - no branches in the loop).
+// (Measured and dropped: waves 4-6 running the PV product of block k - 1 at the start of iteration k: the same time.)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool V> struct FaBool { static constexpr bool value = V; };
 
 #ifdef HALO_STAMP
 // diagnostic build only (make -B EXTRA=-DHALO_STAMP): per-wave s_memtime stamps of the attention kernel, first 1024 workgroups:
-// [0] entry, [1] Q landed, [2] prologue DMA issued, then per key block {barrier passed, S done, softmax done, PV done}, [31] exit
+// [0] entry, [31] exit; of the workgroup's SECOND item (its first when it has only one): [1] item start, then per key block
+// {barrier passed, S done, softmax done, PV done}, [2] stores issued
 __device__ unsigned long long g_attn_stamps[1024 * 7 * 32];
 extern "C" int fp_dbg_attn_stamps(unsigned long long *host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)) == hipSuccess ? 0 : -1;
 }
-#define ASTAMP(i) do { if (blockIdx.x < 1024) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ASTAMP(i) do { if (blockIdx.x < 1024 && stamp_on) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ASTAMP(i) do { } while (0)
 #endif
@@ -77,28 +87,29 @@ __device__ __forceinline__ void at_glds16s(const f16 *sbase, unsigned voff_bytes
 }
 
 __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__restrict__ qk, const f16 *__restrict__ vt, int T,
-                                                                  f16 *__restrict__ out, const f16 *__restrict__ zero_page) {
+                                                                  f16 *__restrict__ out, int n_items) {
   extern __shared__ __attribute__((aligned(16))) f16 smem[];
   const int nqb = (T + FA_QB - 1) / FA_QB;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);          // the query blocks of one (hypothesis, head) share an XCD L2
-  const int qb = L % nqb, h = (L / nqb) & 3, b = L / (nqb * 4);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const size_t rowbase = (size_t)b * T;
-  const f16 *kbase = qk + rowbase * 1024 + 512 + h * AT_DH;              // K row `key` starts at kbase + key*1024
-  const f16 *vsrc = vt + ((size_t)b * 4 + h) * AT_DH * AT_TP;
   const int nkb = (T + FA_KB - 1) / FA_KB;
-
-  // Q^T fragments: loaded by inline asm and waited for by hand BEFORE the first LDS-DMA is issued.  With a
-  // compiler-visible load, hipcc sinks it below the DMAs and then drains vmcnt(0) at the first use of qf inside
-  // the key loop - every iteration - which serialises the whole DMA ring.
+  const int G = gridDim.x;
+  f16 *qlds = smem + FA_NSTAGE * FA_STAGE_HALFS + wave * FA_QW_HALFS;
 #ifdef HALO_STAMP
   unsigned long long st[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) st[i] = 0;
+  bool stamp_on = true;
 #endif
   ASTAMP(0);
-  const int q = qb * FA_QB + wave * 32 + lr;
+
+  // item v (virtual workgroup id: v & 7 = the XCD of this workgroup, the query blocks of one (hypothesis, head) share an XCD L2)
+  auto item_of = [&](int v, int &b, int &h, int &qb) __attribute__((always_inline)) {
+    const int L = xcd_remap(v, n_items);
+    qb = L % nqb;
+    h = (L / nqb) & 3;
+    b = L / (nqb * 4);
+  };
 
   // ---- DMA slots: instruction i = wave + 7u (mod 32) of a stage; i < 16 -> 64 lanes of the K block (64 keys x 16 chunks),
   // else of the V^T block (128 dims x 8 chunks of 8 keys).  Byte offset from the scalar base of a slot for key block kb:
@@ -120,44 +131,44 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
       sadd[u] = d * AT_TP * 2;
     }
   }
-  auto stage = [&](int kb, int buf) __attribute__((always_inline)) {
+  // staging cursor: the next key block the DMA brings in - (item s_v, block s_kb) into ring slot s_slot
+  int s_v = blockIdx.x, s_kb = 0, s_slot = 0;
+  const f16 *s_kbase, *s_vsrc;
+  auto stage_bases = [&]() __attribute__((always_inline)) {
+    int b, h, qb;
+    item_of(s_v, b, h, qb);
+    s_kbase = qk + (size_t)b * T * 1024 + 512 + h * AT_DH;              // K row `key` starts at kbase + key*1024
+    s_vsrc = vt + ((size_t)b * 4 + h) * AT_DH * AT_TP;
+  };
+  stage_bases();
+  auto stage_next = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < FA_DMA_PER_WAVE; ++u) {              // exactly FA_DMA_PER_WAVE per wave (vmcnt accounting)
       int i = wave + u * FA_WAVES;
       if (i >= 32) i -= 32;
       const bool is_k = i < 16;                              // wave-uniform
-      const unsigned t = min((unsigned)(kb * FA_KB) + sx[u], is_k ? (unsigned)(T - 1) : 408u);
+      const unsigned t = min((unsigned)(s_kb * FA_KB) + sx[u], is_k ? (unsigned)(T - 1) : 408u);
       const unsigned voff = t * (is_k ? 2048u : 2u) + sadd[u];
-      at_glds16s(is_k ? kbase : vsrc, voff, smem + buf * FA_STAGE_HALFS + i * 512);
+      at_glds16s(is_k ? s_kbase : s_vsrc, voff, smem + s_slot * FA_STAGE_HALFS + i * 512);
+    }
+    s_slot = s_slot + 1 == FA_NSTAGE ? 0 : s_slot + 1;
+    if (++s_kb == nkb) {
+      s_kb = 0;
+      s_v += G;
+      if (s_v < n_items) stage_bases();
     }
   };
-  // Prologue: both key blocks' DMAs first, then Q^T - the Q latency hides under theirs (a workgroup is alone on its CU:
-  // nothing else covers its start-up; stamps: Q 7.5k + DMA issue 2.9k + block-0 wait 6.8k of a 47k-cycle life when Q was
-  // loaded and waited for first).  Q^T fragments are loaded by inline asm and waited for by hand, the wait directly behind
-  // the loads: with a compiler-visible load, hipcc sinks it below the DMAs and then drains vmcnt(0) at the first use of qf
-  // inside the key loop - every iteration - which serialises the whole DMA ring; with other code between the asm loads and
-  // the asm wait it may copy the destination registers before the data has landed.
+  // Q^T of item v -> this wave's staging area, in fragment order: instruction s, lane (lr, lh) = dims 16 s + 8 lh .. + 8 of query lr.
+  // Query rows past T repeat row T - 1 (finite operands; their columns are never stored).
+  const unsigned qrow = wave * 32 + lr;
+  auto stage_q = [&](int v) __attribute__((always_inline)) {
+    int b, h, qb;
+    item_of(v, b, h, qb);
+    const f16 *qbase = qk + ((size_t)b * T + qb * FA_QB) * 1024 + h * AT_DH;
+    const unsigned voff = min(qrow, (unsigned)(T - 1 - qb * FA_QB)) * 2048u + lh * 16;
 #pragma unroll
-  for (int p = 0; p < FA_AHEAD; ++p)
-    if (p < nkb) stage(p, p);
-  ASTAMP(1);
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 qv[8];
-  {
-    const f16 *qsrc = q < T ? qk + (rowbase + q) * 1024 + h * AT_DH + lh * 8 : zero_page;
-    const int step = q < T ? 16 : 0;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qv[s]) : "v"(qsrc + s * step) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]), "+v"(qv[4]), "+v"(qv[5]), "+v"(qv[6]), "+v"(qv[7])
-                 :
-                 : "memory");
-  }
-  half8 qf[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<half8 *>(&qv[s]);
-  __builtin_amdgcn_sched_barrier(0);
-  ASTAMP(2);
+    for (int s = 0; s < 8; ++s) at_glds16s(qbase + s * 16, voff, qlds + s * 512);
+  };
 
   // ---- LDS fragment offsets (bytes, within a stage) ----
   //   K: row (kt*32 + lr), chunk (2*s + lh) ^ (lr & 15), s = 0..7; kt adds 8192 B
@@ -168,148 +179,204 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
 #pragma unroll
   for (int s = 0; s < 4; ++s) voffb[s] = FA_KB * AT_DH * 2 + (lr * FA_KB + (((2 * s + lh) ^ ((lr >> 1) & 7)) * 8)) * 2;
 
-  floatx16 oacc[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;
   const float c2 = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128): exp((s-m)/sqrt(128)) = exp2(s*c2 - m*c2)
   const f32x2 c2v = {c2, c2};
 
-  // One key block of one wave: S^T -> softmax -> P^T (packed fp16), and O^T += V^T P^T.  Waves 4-6 (the second wave on
-  // their SIMD) run the PV product of block kb-1 at the START of iteration kb and keep P^T across the barrier, so a SIMD
-  // pairs one wave's MFMAs with the other's softmax instead of running the same phase on both (FA_STAGGER).
-  half8 pfc[2][2];                                             // P^T of the block whose PV product is still owed (late waves)
-  auto pv_phase = [&](const int kb, const half8 (&pf)[2][2]) __attribute__((always_inline)) {
-    const char *sb = reinterpret_cast<const char *>(smem) + (kb % FA_NSTAGE) * (FA_STAGE_HALFS * 2);
+  // Prologue of the workgroup (the only start-up nothing covers): two key blocks, then Q^T of the first item.
+  int inflight = 0;                                            // key blocks staged and not consumed yet (the current one included)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      half8 vf[2][4];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vf[s2][dt] = *reinterpret_cast<const half8 *>(sb + voffb[kt * 2 + s2] + dt * (32 * FA_KB * 2));
-      __builtin_amdgcn_sched_barrier(0);                     // eight V^T reads in flight before the first MFMA waits
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][dt], pf[kt][s2], oacc[dt], 0, 0, 0);
+  for (int p = 0; p < FA_AHEAD; ++p)
+    if (s_v < n_items) {
+      stage_next();
+      ++inflight;
     }
-  };
-  auto body = [&](const int kb, auto tail_c, auto late_c) __attribute__((always_inline)) {
-    constexpr bool TAIL = decltype(tail_c)::value;           // this block holds keys >= T
-    constexpr bool LATE = decltype(late_c)::value;
-    // block kb must have landed; the next block stays in flight across the barrier
-    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    ASTAMP(3 + 4 * kb);
-    // ring slot of block kb-2: every wave is past it (the late waves finished PV(kb-2) in iteration kb-1)
-    if (kb + FA_AHEAD < nkb) stage(kb + FA_AHEAD, (kb + FA_AHEAD) % FA_NSTAGE);
-    if constexpr (LATE) {
-      if (kb > 0) pv_phase(kb - 1, pfc);
-    }
-    const char *sb = reinterpret_cast<const char *>(smem) + (kb % FA_NSTAGE) * (FA_STAGE_HALFS * 2);
-    floatx16 sacc[2];
-    // two independent accumulation chains (key tiles 0/1), fragments fetched four k-steps at a time so that
-    // eight LDS reads are in flight before the first MFMA of the group issues
+  stage_q((int)blockIdx.x);
+
+  half8 qf[8];
+  floatx16 oacc[4];
+  float m_run, l_run;
+  int c_slot = 0;                                              // ring slot of the block being consumed
+  int st_prev = 0;                                             // stores this wave issued at the end of the previous item
+  bool first = true;
+
+  for (int v = blockIdx.x; v < n_items; v += G) {
+    int b, h, qb;
+    item_of(v, b, h, qb);
+    const size_t rowbase = (size_t)b * T;
+    const int q = qb * FA_QB + wave * 32 + lr;
+    const bool wave_valid = qb * FA_QB + wave * 32 < T;         // wave-uniform: some query of this wave exists
+    const bool has_next = v + G < n_items;
+#ifdef HALO_STAMP
+    stamp_on = v == (int)blockIdx.x + G || n_items <= G;
+#endif
+    ASTAMP(1);
 #pragma unroll
-    for (int sh = 0; sh < 2; ++sh) {
-      half8 kf[2][4];
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+    m_run = -1.0e30f;
+    l_run = 0.f;
+
+    auto body = [&](const int kb, auto first_c, auto tail_c) __attribute__((always_inline)) {
+      constexpr bool KB0 = decltype(first_c)::value;           // kb == 0: this item's Q^T comes out of LDS, the next item's goes in
+      constexpr bool TAIL = decltype(tail_c)::value;           // this block may hold keys >= T
+      // Block (v, kb) must have landed - and in iteration 0 this item's Q^T.  `allowed` = operations issued after it that may stay in
+      // flight: the next block (5), in iteration 0 the stores of the previous item (issued after that block's DMA), in iteration 1 the
+      // next item's Q^T (issued in iteration 0 behind the block two ahead).  The first item's Q^T is the youngest operation: drain.
+      int allowed = inflight > 1 ? 5 : 0;
+      if (KB0) allowed = first ? 0 : (nkb == 1 ? st_prev : allowed + st_prev);
+      else if (kb == 1 && has_next) allowed += 8;
+      if (allowed == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if (allowed == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      else if (allowed == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      ASTAMP(3 + 4 * kb);
+      // ring slot of block p - 1: every wave is past it
+      if (s_v < n_items) {
+        stage_next();
+        ++inflight;
+      }
+      if constexpr (KB0) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) kf[kt][s] = *reinterpret_cast<const half8 *>(sb + koffb[sh * 4 + s] + kt * (32 * AT_DH * 2));
-      __builtin_amdgcn_sched_barrier(0);                     // all eight reads issue before the first MFMA waits for one
+        for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const half8 *>(qlds + s * 512 + lane * 8);
+      }
+      const char *sb = reinterpret_cast<const char *>(smem) + c_slot * (FA_STAGE_HALFS * 2);
+      floatx16 sacc[2];
+      // two independent accumulation chains (key tiles 0/1), fragments fetched four k-steps at a time so that
+      // eight LDS reads are in flight before the first MFMA of the group issues
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int sh = 0; sh < 2; ++sh) {
+        half8 kf[2][4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-          if (sh == 0 && s == 0) {
-            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[0], zero, 0, 0, 0);
-          } else {
-            sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[sh * 4 + s], sacc[kt], 0, 0, 0);
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) kf[kt][s] = *reinterpret_cast<const half8 *>(sb + koffb[sh * 4 + s] + kt * (32 * AT_DH * 2));
+        __builtin_amdgcn_sched_barrier(0);                     // all eight reads issue before the first MFMA waits for one
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            if (sh == 0 && s == 0) {
+              const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[0], zero, 0, 0, 0);
+            } else {
+              sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[sh * 4 + s], sacc[kt], 0, 0, 0);
+            }
           }
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    ASTAMP(4 + 4 * kb);
-    // ---- online softmax for query column lr ----
-    if constexpr (TAIL) {                                   // keys >= T: score -1e30 -> out of the max, exp2 -> exactly 0
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ASTAMP(4 + 4 * kb);
+      // the S^T MFMAs have consumed all eight Q^T fragments (their ds_reads are complete): the staging area is free for the next item's
+      if constexpr (KB0) {
+        if (has_next) stage_q(v + G);
+      }
+      // ---- online softmax for query column lr ----
+      if constexpr (TAIL) {                                   // keys >= T: score -1e30 -> out of the max, exp2 -> exactly 0
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kb * FA_KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sacc[kt][r] = key < T ? sacc[kt][r] : -1.0e30f;
+          }
+      }
+      float bm = fmaxf(sacc[0][15], sacc[1][15]);              // compiler-visible first reader of both accumulators
+      bm = fa_max3(bm, sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int r = 1; r < 15; r += 2) bm = fa_max3(bm, sacc[0][r], sacc[0][r + 1]);
+#pragma unroll
+      for (int r = 1; r < 15; r += 2) bm = fa_max3(bm, sacc[1][r], sacc[1][r + 1]);
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      const float m_new = fmaxf(m_run, bm);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+      const float nmc = -m_new * c2;
+      const f32x2 nmcv = {nmc, nmc};
+      f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb * FA_KB + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          sacc[kt][r] = key < T ? sacc[kt][r] : -1.0e30f;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 sv = {sacc[kt][r], sacc[kt][r + 1]};
+          const f32x2 ev = __builtin_elementwise_fma(sv, c2v, nmcv);
+          const f32x2 e = {__builtin_amdgcn_exp2f(ev.x), __builtin_amdgcn_exp2f(ev.y)};
+          sacc[kt][r] = e.x;
+          sacc[kt][r + 1] = e.y;
+          ps2 += e;
         }
-    }
-    float bm = fmaxf(sacc[0][15], sacc[1][15]);              // compiler-visible first reader of both accumulators
-    bm = fa_max3(bm, sacc[0][0], sacc[1][0]);
+      float ps = ps2.x + ps2.y;
+      ps += __shfl_xor(ps, 32);
+      l_run = l_run * alpha + ps;
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {    // some lane's maximum moved: rescale O^T (alpha == 1 elsewhere)
 #pragma unroll
-    for (int r = 1; r < 15; r += 2) bm = fa_max3(bm, sacc[0][r], sacc[0][r + 1]);
+        for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-    for (int r = 1; r < 15; r += 2) bm = fa_max3(bm, sacc[1][r], sacc[1][r + 1]);
-    bm = fmaxf(bm, __shfl_xor(bm, 32));
-    const float m_new = fmaxf(m_run, bm);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-    const float nmc = -m_new * c2;
-    const f32x2 nmcv = {nmc, nmc};
-    f32x2 ps2 = {0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const f32x2 sv = {sacc[kt][r], sacc[kt][r + 1]};
-        const f32x2 ev = __builtin_elementwise_fma(sv, c2v, nmcv);
-        const f32x2 e = {__builtin_amdgcn_exp2f(ev.x), __builtin_amdgcn_exp2f(ev.y)};
-        sacc[kt][r] = e.x;
-        sacc[kt][r + 1] = e.y;
-        ps2 += e;
+          for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
       }
-    float ps = ps2.x + ps2.y;
-    ps += __shfl_xor(ps, 32);
-    l_run = l_run * alpha + ps;
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {    // some lane's maximum moved: rescale O^T (alpha == 1 elsewhere)
+      m_run = m_new;
+      // ---- P^T, and O^T += V^T P^T ----
+      half8 pf[2][2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[kt][s2][j] = (f16)sacc[kt][8 * s2 + j];
+      __builtin_amdgcn_sched_barrier(0);
+      ASTAMP(5 + 4 * kb);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        half8 vf[2][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) vf[s2][dt] = *reinterpret_cast<const half8 *>(sb + voffb[kt * 2 + s2] + dt * (32 * FA_KB * 2));
+        __builtin_amdgcn_sched_barrier(0);                     // eight V^T reads in flight before the first MFMA waits
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s2][dt], pf[kt][s2], oacc[dt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ASTAMP(6 + 4 * kb);
+      c_slot = c_slot + 1 == FA_NSTAGE ? 0 : c_slot + 1;
+      --inflight;
+    };
+    // the last block always runs the tail form (the mask is the identity when T is a multiple of 64)
+    if (nkb == 1) {
+      body(0, FaBool<true>{}, FaBool<true>{});
+    } else {
+      body(0, FaBool<true>{}, FaBool<false>{});
+      for (int kb = 1; kb < nkb - 1; ++kb) body(kb, FaBool<false>{}, FaBool<false>{});
+      body(nkb - 1, FaBool<false>{}, FaBool<true>{});
+    }
+
+    // O^T accumulator: col = query lr, row = dim (r&3) + 8*(r>>2) + 4*lh of each 32-dim tile: a query's output row is split across
+    // the two halves of the wave (lane: dims 8g .. 8g+3, lane + 32: 8g+4 .. 8g+7).  One v_permlane32_swap per dword and pair of
+    // dim groups (g, g+1) leaves lanes 0-31 with dims 8g .. 8g+7 and lanes 32-63 with 8g+8 .. 8g+15: 8 16-byte stores per lane instead
+    // of 16 8-byte ones (the store tail is issue-bound: cdna_hip_programming.md T21).  The swaps need every lane: only the store is masked.
+    if (wave_valid) {                                            // wave-uniform: exactly 8 store instructions, or none (vmcnt accounting)
+      const float inv = 1.f / l_run;
+      f16 *orow = out + (rowbase + min(q, T - 1)) * 512 + h * AT_DH + lh * 8;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[dt][e] *= alpha;
+        for (int gq = 0; gq < 4; gq += 2) {
+          half4 ha, hb;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ha[j] = (f16)(oacc[dt][gq * 4 + j] * inv), hb[j] = (f16)(oacc[dt][(gq + 1) * 4 + j] * inv);
+          const uint2 ua = __builtin_bit_cast(uint2, ha), ub = __builtin_bit_cast(uint2, hb);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+          const uint4 ov = {r0[0], r1[0], r0[1], r1[1]};
+          if (q < T) *reinterpret_cast<uint4 *>(orow + dt * 32 + gq * 8) = ov;
+        }
     }
-    m_run = m_new;
-    // ---- P^T, and O^T += V^T P^T now (early waves) or at the start of the next iteration (late waves) ----
-    half8 pf[2][2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[kt][s2][j] = (f16)sacc[kt][8 * s2 + j];
-    __builtin_amdgcn_sched_barrier(0);
-    ASTAMP(5 + 4 * kb);
-    if constexpr (LATE) {
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) pfc[kt][s2] = pf[kt][s2];
-    } else {
-      pv_phase(kb, pf);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    ASTAMP(6 + 4 * kb);
-  };
-  auto run = [&](auto late_c) __attribute__((always_inline)) {
-    for (int kb = 0; kb < nkb - 1; ++kb) body(kb, FaBool<false>{}, late_c);
-    if (nkb * FA_KB > T) body(nkb - 1, FaBool<true>{}, late_c);
-    else body(nkb - 1, FaBool<false>{}, late_c);
-    if constexpr (decltype(late_c)::value) pv_phase(nkb - 1, pfc);
-  };
-  if (FA_STAGGER && wave >= 4) run(FaBool<true>{});
-  else run(FaBool<false>{});
-
+    ASTAMP(2);
+    st_prev = wave_valid ? 8 : 0;
+    first = false;
+  }
 #ifdef HALO_STAMP
   if (blockIdx.x < 1024 && lane == 0) {
     st[31] = __builtin_amdgcn_s_memtime();
@@ -318,41 +385,20 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
     for (int i = 0; i < 32; ++i) o[i] = st[i];
   }
 #endif
-  // O^T accumulator: col = query lr, row = dim (r&3) + 8*(r>>2) + 4*lh of each 32-dim tile: a query's output row is split across
-  // the two halves of the wave (lane: dims 8g .. 8g+3, lane + 32: 8g+4 .. 8g+7).  One v_permlane32_swap per dword and pair of
-  // dim groups (g, g+1) leaves lanes 0-31 with dims 8g .. 8g+7 and lanes 32-63 with 8g+8 .. 8g+15: 8 16-byte stores per lane instead
-  // of 16 8-byte ones (the store tail is issue-bound: cdna_hip_programming.md T21).  The swaps need every lane: only the store is masked.
-  {
-    const float inv = 1.f / l_run;
-    f16 *orow = out + (rowbase + min(q, T - 1)) * 512 + h * AT_DH + lh * 8;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int gq = 0; gq < 4; gq += 2) {
-        half4 ha, hb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ha[j] = (f16)(oacc[dt][gq * 4 + j] * inv), hb[j] = (f16)(oacc[dt][(gq + 1) * 4 + j] * inv);
-        const uint2 ua = __builtin_bit_cast(uint2, ha), ub = __builtin_bit_cast(uint2, hb);
-        const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
-        const uint4 v = {r0[0], r1[0], r0[1], r1[1]};
-        if (q < T) *reinterpret_cast<uint4 *>(orow + dt * 32 + gq * 8) = v;
-      }
-  }
 }
 
 int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s) {
   FP_REQUIRE(T > 0 && T <= AT_MAXT, "attention: T=%d must be in [1,%d]", T, AT_MAXT);
   if (B == 0) return FP_OK;
-  const size_t lds = FA_NSTAGE * FA_STAGE_HALFS * sizeof(f16);
   static bool attr_set = false;       // once: not a stream operation (and not wanted inside a graph capture)
   if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FP_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FA_LDS_BYTES));
     attr_set = true;
   }
-  dim3 grid(((T + FA_QB - 1) / FA_QB) * 4 * B);
+  const int n_items = ((T + FA_QB - 1) / FA_QB) * 4 * B;
+  const int grid = n_items < ctx->num_cu ? n_items : ctx->num_cu;        // one persistent workgroup per CU (152 KB of LDS each)
   ProfScope ps(ctx, s, "attention", 4.0 * B * 4 * (double)T * T * AT_DH);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(FA_THREADS), lds, s, qk, vt, T, out, (const f16 *)ctx->zero_page);
+  hipLaunchKernelGGL(attention_kernel, dim3(grid), dim3(FA_THREADS), FA_LDS_BYTES, s, qk, vt, T, out, n_items);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -507,6 +507,39 @@ def test_attention_vs_reference(fp, T):
   assert err <= 2e-3, err
 
 
+@pytest.mark.parametrize('B,T', [(130, 400), (70, 400), (300, 37), (140, 230), (270, 64), (90, 130), (33, 400)])
+def test_attention_persistent_items_equal_single_items(fp, B, T):
+  """More (hypothesis, head, query block) items than CUs: a workgroup walks several items and its DMA ring, Q^T staging and store
+  accounting run across the item boundaries.  The arithmetic of an item does not depend on that, so the batch must equal launches
+  of at most 256 items (one item per workgroup: no boundary inside a workgroup) BIT FOR BIT, and the fp32 reference within the
+  kernel's tolerance.  (300, 37): one key block per item; (140, 230): second query block partly empty (waves without queries issue no
+  stores); (270, 64): no key tail; (90, 130): three key blocks; (33, 400): 264 items - only 8 workgroups get a second one."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  g = torch.Generator(device='cuda').manual_seed(100 + B + T)
+  qk = (torch.randn((B * T, 1024), device='cuda', generator=g) * 1.5).half()
+  vt = torch.zeros((B, 4, 128, 416), device='cuda', dtype=torch.float16)
+  t = np.arange(T)
+  col = (t & ~15) | (((t >> 2) & 1) << 3) | (((t >> 3) & 1) << 2) | (t & 3)
+  v = torch.randn((B, 4, 128, T), device='cuda', generator=g).half()
+  vt[..., torch.from_numpy(col).cuda()] = v
+  out = torch.full((B * T, 512), float('nan'), dtype=torch.float16, device='cuda')
+  check(lib().fp_attention_f16(fp['ctx'].handle, ptr(qk), ptr(vt), B, T, ptr(out), stream_ptr()))
+  nqb = -(-T // 224)
+  step = max(1, 256 // (4 * nqb))
+  ref16 = torch.full_like(out, float('nan'))
+  for b0 in range(0, B, step):
+    nb = min(step, B - b0)
+    check(lib().fp_attention_f16(fp['ctx'].handle, ptr(qk[b0 * T:]), ptr(vt[b0:]), nb, T, ptr(ref16[b0 * T:]), stream_ptr()))
+  torch.cuda.synchronize()
+  assert not bool(torch.isnan(out).any())
+  assert torch.equal(out, ref16)
+  q = qk[:, :512].float().reshape(B, T, 4, 128).transpose(1, 2)
+  k = qk[:, 512:].float().reshape(B, T, 4, 128).transpose(1, 2)
+  vv = v.float().permute(0, 1, 3, 2)
+  ref = (torch.softmax(q @ k.transpose(-1, -2) / 128 ** 0.5, -1) @ vv).transpose(1, 2).reshape(B * T, 512)
+  assert float((out.float() - ref).abs().max()) <= 2e-3
+
+
 def test_attention_run_to_run_identical(fp):
   """Regression: an inline-asm v_max3 that was the first reader of the S accumulators (no hazard wait states inside asm)
   read half-written MFMA results - within tolerance (softmax is shift-invariant) but different from run to run."""
