@@ -91,14 +91,15 @@ def step_finalize(est, objects, world, rank, gathered, everywhere=False):
   """The cross-hypothesis tail of the objects this rank finalises (object o: rank o % world; `everywhere`: all of them on
   every rank).  gathered: every rank's row block, (world * n_objects * shard, 528) in rank order.
   Returns {object: (argmax, poses (252,4,4))}."""
-  from foundationpose_amd.dist import gather_order, unpack_rows
+  from foundationpose_amd.dist import gather_order_index, unpack_rows
   shard = math.ceil(N_HYP / world)
   gathered = gathered.reshape(world, len(objects), shard, -1)
   results = {}
   for o in range(len(objects)):
     if not everywhere and o % world != rank:
       continue
-    feats_all, poses_all = unpack_rows(gathered[gather_order(o, world), o].reshape(world * shard, -1), N_HYP, world)
+    mine = gathered[0, o] if world == 1 else gathered[gather_order_index(o, world, gathered.device), o]
+    feats_all, poses_all = unpack_rows(mine.reshape(world * shard, -1), N_HYP, world)
     logits, am = est.scorer.score_tail(feats_all, L=N_HYP)
     results[o] = (am, poses_all)
   return results

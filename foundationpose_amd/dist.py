@@ -34,9 +34,23 @@ def gather_order(obj, world):
   return [(s - obj) % world for s in range(world)]
 
 
+_ORDER_INDEX = {}
+
+
+def gather_order_index(obj, world, device):
+  """gather_order as an index tensor on `device`, built once: indexing with a Python list uploads an index tensor on every call, and
+  that host-to-device copy makes the host wait for the stream (the GPU then idles between the small launches that follow)."""
+  key = (obj % world, world, str(device))
+  if key not in _ORDER_INDEX:
+    _ORDER_INDEX[key] = torch.as_tensor(gather_order(obj, world), dtype=torch.long, device=device)
+  return _ORDER_INDEX[key]
+
+
 def pack_rows(feats, poses, shard_size):
   """(k,512) feats + (k,4,4) poses -> (shard_size, 528) rows, zero padded (k <= shard_size)."""
   k = feats.shape[0]
+  if k == shard_size:                      # a full shard: one copy, no padding pass
+    return torch.cat((feats, poses.reshape(k, 16)), 1)
   rows = torch.zeros((shard_size, ROW), dtype=torch.float32, device=feats.device)
   if k:
     rows[:k, :512] = feats
@@ -47,10 +61,10 @@ def pack_rows(feats, poses, shard_size):
 def unpack_rows(gathered, n, world):
   """(world*shard_size, 528) all-gathered rows -> feats (n,512), poses (n,4,4) in hypothesis order."""
   shard = gathered.shape[0] // world
-  keep = []
-  for r, (a, b) in enumerate(shard_ranges(n, world)):
-    keep.append(gathered[r * shard:r * shard + (b - a)])
-  rows = torch.cat(keep, 0)
+  if n == world * shard:                   # every shard full: the gathered block is the row list
+    rows = gathered
+  else:
+    rows = torch.cat([gathered[r * shard:r * shard + (b - a)] for r, (a, b) in enumerate(shard_ranges(n, world))], 0)
   return rows[:, :512].contiguous(), rows[:, 512:].reshape(-1, 4, 4).contiguous()
 
 
