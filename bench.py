@@ -413,7 +413,7 @@ def main(argv=None):
                                                     f'all-gather of [feature|pose] rows, cross-hypothesis tail + argmax on every rank'),
                  'hypotheses_per_object': N_HYP, 'objects': 1, 'est_refine_iter': ITER, 'parallelism': f'hyp-shard x{world}',
                  'weights': 'seeded random (reference state_dict layout)'},
-      'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_halo_dma_kernel (3x3 stride-1 convolutions: 93 % of the conv FLOPs)',
+      'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_halo_dma_kernel + conv3x3_s1_band_kernel (the 3x3 stride-1 convolutions, 93 % of the conv FLOPs; the band form runs the 128 -> 128 layers, bit-identical)',
                    'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F16_TFLOPS,
                    'launches': conv['launches'], 'flops_per_launch': conv['flops'] / max(conv['launches'], 1),
                    'busy_ms': busy_ms, 'avg_launch_ms': busy_ms / max(conv['launches'], 1),

@@ -732,6 +732,43 @@ extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int
   return launch_conv(ctx, a, (hipStream_t)stream);
 }
 
+// Building block for the parity tests: the band-in-LDS form of the 128 -> 128 3x3 stride-1 layers on 40x40 maps (conv_s1b.hip), which
+// the networks use for batches of >= 8 hypotheses; same operands as fp_conv2d_f16 (w_packed [128][1152] fp16).
+extern "C" int fp_conv3x3_c128_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, const void *d_w_packed, const float *d_bias, const void *d_res,
+                                        int relu, void *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_in && d_w_packed && d_bias && d_out && Nimg >= 0, "fp_conv3x3_c128_band_f16: bad argument");
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = (const f16 *)d_in;
+  a.w = (const f16 *)d_w_packed;
+  a.bias = d_bias;
+  a.res = (const f16 *)d_res;
+  a.out = d_out;
+  a.Nimg = Nimg;
+  a.H = a.W = a.Ho = a.Wo = 40;
+  a.Cin = a.Cout = 128;
+  a.KH = a.KW = 3;
+  a.stride = 1;
+  a.pad = 1;
+  a.Kpad = 9 * 128;
+  a.M = Nimg * 1600;
+  a.relu = relu;
+  a.out_ld = 128;
+  a.split_m = 0x7fffffff;
+  a.post_period = 1;
+  a.tokens = 400;
+  if (a.M == 0) return FP_OK;
+  const size_t bytes = s2_packed_halfs(128, 128) * sizeof(f16);
+  FP_TRY(fp_arena_ensure(ctx, bytes + 4096));
+  const size_t mark = ctx->arena.off;
+  f16 *pk = (f16 *)ctx->arena.take(bytes);
+  int rc = pk ? s2_pack_weights(a.w, 128, 128, a.Kpad, pk, (hipStream_t)stream, 2, 1) : FP_ENOMEM;
+  a.wpk = pk;
+  if (rc == FP_OK) rc = launch_conv_s1b(ctx, a, (hipStream_t)stream);
+  ctx->arena.off = mark;
+  return rc;
+}
+
 extern "C" int fp_attention_f16(fp_ctx *ctx, const void *d_qk, const void *d_vt, int B, int T, void *d_out, void *stream) {
   FP_REQUIRE(ctx && d_qk && d_vt && d_out, "fp_attention_f16: null argument");
   return launch_attention(ctx, (const f16 *)d_qk, (const f16 *)d_vt, B, T, (f16 *)d_out, (hipStream_t)stream);

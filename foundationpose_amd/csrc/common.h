@@ -217,9 +217,9 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 bool s2_supported(const ConvArgs &a);
 int s2_ct_for(int Cout);
 size_t s2_packed_halfs(int Cout, int Cin);
-int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s, int ct_force = 0);   // ct_force: co tiles of 32 per wave group (0: s2_ct_for)
+int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s, int ct_force = 0, int order = 0);   // ct_force: co tiles of 32 per wave group (0: s2_ct_for); order 1: conv_s1b.hip
 int launch_conv_s2(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
-// conv_s1b.hip: band-in-LDS form of the 128 -> 128 stride-1 layers on 40x40 maps (experiment, FP_C128_BAND=1)
+// conv_s1b.hip: band-in-LDS form of the 128 -> 128 stride-1 layers on 40x40 maps (bit-identical to the halo kernel; FP_C128_BAND=0: off)
 bool s1b_supported(const ConvArgs &a);
 int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 

@@ -1,24 +1,23 @@
 // 3x3 / stride-1 / pad-1 convolution 128 -> 128 on 40x40 maps (the four ResnetBasicBlock convolutions of encodeA / encoderA,
-// network_modules.py:73-111 via refine_network.py:39-40) on the structure of conv_s2.hip instead of conv_halo.hip: the measured
-// alternative of round 3, selected by FP_C128_BAND=1 for batches of >= 8 hypotheses, OFF by default.  On full-batch
-// launches (504 images, kernel trace): 215 / 242 us without / with residual against 223 / 247 us for conv3x3_halo_dma_kernel<40> -
-// 1106 / 983 against 1067 / 965 TFLOP/s, 0.1 ms of a 36.5-ms step.  Not the default because a different accumulation order (16-channel
-// chunks, taps inside) moves the fp16 noise of the scorer's logits: on one of the twelve full-size fixtures (c3L_3, the smallest
-// top-1 / top-2 margin) the margin falls from 20+ to 15 x that noise - identical argmax, but the fixture's margin rule was set on the
-// halo kernel, and 0.1 ms does not buy re-tuning a parity fixture.
+// network_modules.py:73-111 via refine_network.py:39-40) on the structure of conv_s2.hip instead of conv_halo.hip.
+// Bit-identical to conv3x3_halo_dma_kernel<40>: an output element accumulates in the same order - 32-channel groups, inside a group
+// kernel row by kernel row, inside a row tap by tap, inside a tap the two 16-channel MFMA steps - from the same bias, and the epilogue
+// rounds once after the same fp32 residual add (tests/test_gpu_kernels.py::test_c128_band_kernel_equals_halo_kernel).  Full-batch launches
+// (504 images, kernel trace, first form with 16-channel chunks): 215 / 242 us without / with residual against 223 / 247 us.
 //
 // With four K chunks of 32 channels the 8-wave halo kernel spends 39 % of a workgroup's life in prologue and epilogue, one workgroup
 // per CU.  Here
 //   * a workgroup (4 waves) owns 8 output rows x 40 = 320 pixels of ONE image (5 tiles per image: no tile straddles two) x all 128
 //     output channels: wave (c, p) owns 64 couts (2 accumulator tiles) x the 160 pixels of rows 4p .. 4p+3 (5 pixel tiles of 32);
-//   * per 16-channel chunk the band (10 input rows x 42 columns of 32-byte pixels, row pitch 56 slots: 56 = 40 (mod 16) keeps the lane ->
-//     bank map of a 32-pixel tile unchanged across its row breaks; the two 16-byte halves of slot q swapped when bit 3 of q is set) goes
-//     to LDS once by LDS-DMA, double buffered, and feeds all 9 taps;
-//   * weights never touch LDS: packed at load time in MFMA-fragment order (s2_pack_weights), each wave streams the fragments of its 64
-//     couts L2 -> registers three taps ahead: 2 KB per 10 MFMAs;
-//   * two workgroups per CU (40 KB LDS, <= 256 VGPRs each).
+//   * per 32-channel group the band goes to LDS once by LDS-DMA as two 16-channel planes (10 input rows x 42 columns of 32-byte
+//     pixels each, row pitch 56 slots: 56 = 40 (mod 16) keeps the lane -> bank map of a 32-pixel tile unchanged across its row breaks;
+//     the two 16-byte halves of slot q swapped when bit 3 of q is set), double buffered (72 KB), and feeds all 9 taps of both planes;
+//   * weights never touch LDS: packed at load time in MFMA-fragment order (s2_pack_weights, order 1: group, tap, 16-channel half,
+//     co tile), each wave streams the fragments of its 64 couts L2 -> registers three steps ahead: 2 KB per 10 MFMAs;
+//   * two workgroups per CU (<= 256 VGPRs each).
 // Epilogue: accumulators start at the folded BN bias; residual rows staged through LDS and added in fp32, ReLU, one rounding to fp16,
 // 16-byte NHWC stores (with the channel-concat addressing of the last encodeA layer: out_ld / split_m / coff_hi).
+// FP_C128_BAND=0 sends these layers back to the halo kernel.
 #include "common.h"
 
 #define B1_THREADS 256
@@ -26,7 +25,8 @@
 #define B1_ROWS 8
 #define B1_P 56
 #define B1_BROWS (B1_ROWS + 2)
-#define B1_BAND_INSTR 20                                  // 1-KB DMA instructions per chunk: 560 slots of 32 B = 17.5 KB, 5 per wave
+#define B1_PLANE_BYTES (B1_BROWS * B1_P * 32)             // one 16-channel plane of the band: 560 slots of 32 B = 17 920 B (a multiple of 256)
+#define B1_BAND_INSTR 36                                  // 1-KB DMA instructions per 32-channel group (two planes = 35 KB), 9 per wave
 #define B1_BAND_BYTES (B1_BAND_INSTR * 1024)
 #define B1_DPW (B1_BAND_INSTR / 4)
 #define B1_NPT 5
@@ -48,22 +48,24 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)b1_smem;
   const int tile = xcd_remap(blockIdx.x, n_tiles);
   const int img = tile / (H / B1_ROWS), oy0 = (tile - img * (H / B1_ROWS)) * B1_ROWS;
-  const int nch = p.Cin >> 4;
+  const int ngrp = p.Cin >> 5;                             // 32-channel groups
 
-  // ---- band DMA: instruction u = wave + 4 v, lane l -> slot q = 32 u + l/2, physical half l&1 = logical half ^ bit 3 of q ----
-  unsigned src_off[DPW];                                   // byte offset of (pixel, logical half) in the input, chunk 0; ~0u: zeros
+  // ---- band DMA: instruction u = wave + 4 v, lane l -> slot 32 u + l/2 of the group's 1120 (plane ks = slot / 560, slot q of the plane),
+  // physical half l&1 = logical half ^ bit 3 of q ----
+  unsigned src_off[DPW];                                   // byte offset of (pixel, plane, logical half) in the input, group 0; ~0u: zeros
 #pragma unroll
   for (int v = 0; v < DPW; ++v) {
-    const int q = (wave + 4 * v) * 32 + (lane >> 1), hl = (lane & 1) ^ ((q >> 3) & 1);
+    const int qq = (wave + 4 * v) * 32 + (lane >> 1);
+    const int ks = qq >= B1_BROWS * P ? 1 : 0, q = qq - ks * (B1_BROWS * P), hl = (lane & 1) ^ ((q >> 3) & 1);
     const int b = q / P, c = q - b * P;
     const int iy = oy0 - 1 + b, ix = c - 1;
     const bool ok = b < B1_BROWS && c < W + 2 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-    src_off[v] = ok ? (unsigned)((((img * H + iy) * W + ix) * p.Cin + hl * 8) * 2) : 0xffffffffu;
+    src_off[v] = ok ? (unsigned)((((img * H + iy) * W + ix) * p.Cin + ks * 16 + hl * 8) * 2) : 0xffffffffu;
   }
-  auto band_dma = [&](int chunk, int buf) __attribute__((always_inline)) {
+  auto band_dma = [&](int grp, int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int v = 0; v < DPW; ++v) {
-      const char *src = src_off[v] != 0xffffffffu ? (const char *)p.in + src_off[v] + chunk * 32 : (const char *)zero_page;
+      const char *src = src_off[v] != 0xffffffffu ? (const char *)p.in + src_off[v] + grp * 64 : (const char *)zero_page;
       b1_glds16(src, lds0 + buf * B1_BAND_BYTES + (wave + 4 * v) * 1024);
     }
   };
@@ -75,8 +77,8 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
     const int pl = 32 * j + lr, jr = pl / W, ox = pl - jr * W;
     qb[j] = (((4 * ph + jr) * P + ox) << 5) | (lh << 4);
   }
-  // ---- A fragments: this wave's stream of 1-KB fragments, (chunk, tap, co tile) in order (s2_pack_weights, group = cout half) ----
-  const half8 *wp = reinterpret_cast<const half8 *>(wpk) + ((size_t)ch * nch * 9 * CT) * 64 + lane;
+  // ---- A fragments: this wave's stream of 1-KB fragments, (group, tap, 16-channel half, co tile) in order (s2_pack_weights order 1) ----
+  const half8 *wp = reinterpret_cast<const half8 *>(wpk) + ((size_t)ch * ngrp * 18 * CT) * 64 + lane;
   half8 aq[3][CT];
   int f = 0;
   auto a_fetch = [&](int slot) __attribute__((always_inline)) {
@@ -105,33 +107,34 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
         }
       }
   }
-  for (int chunk = 0; chunk < nch; ++chunk) {
+  for (int grp = 0; grp < ngrp; ++grp) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (chunk + 1 < nch) band_dma(chunk + 1, (chunk + 1) & 1);
-    const unsigned char *band = b1_smem + (chunk & 1) * B1_BAND_BYTES;
-    auto b_read = [&](int t, int j) __attribute__((always_inline)) -> half8 {
-      const int ky = t / 3, kx = t - ky * 3;
+    if (grp + 1 < ngrp) band_dma(grp + 1, (grp + 1) & 1);
+    const unsigned char *band = b1_smem + (grp & 1) * B1_BAND_BYTES;
+    // step st = tap * 2 + ks (tap = ky * 3 + kx): the halo kernel's order inside a 32-channel group
+    auto b_read = [&](int st, int j) __attribute__((always_inline)) -> half8 {
+      const int t = st >> 1, ks = st & 1, ky = t / 3, kx = t - ky * 3;
       int x = qb[j];
       asm volatile("" : "+v"(x));
       x += (ky * P + kx) << 5;
-      return *reinterpret_cast<const half8 *>(band + (x ^ ((x >> 4) & 16)));
+      return *reinterpret_cast<const half8 *>(band + ks * B1_PLANE_BYTES + (x ^ ((x >> 4) & 16)));
     };
     half8 b[NPT];
 #pragma unroll
     for (int j = 0; j < NPT; ++j) b[j] = b_read(0, j);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int st = 0; st < 18; ++st) {
 #pragma unroll
       for (int j = 0; j < NPT; ++j) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[ct][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[t % 3][ct], b[j], acc[ct][j], 0, 0, 0);
-        if (t < 8) b[j] = b_read(t + 1, j);
+        for (int ct = 0; ct < CT; ++ct) acc[ct][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[st % 3][ct], b[j], acc[ct][j], 0, 0, 0);
+        if (st < 17) b[j] = b_read(st + 1, j);
         __builtin_amdgcn_sched_barrier(0);
       }
-      a_fetch(t % 3);
+      a_fetch(st % 3);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
 
 bool s1b_supported(const ConvArgs &a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.out_mode == 0 && !a.post_add && a.H == B1_W && a.W == B1_W && a.Cin == 128 &&
-         a.Cout == 128 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0 && a.wpk != nullptr && !(a.splitk && a.ksplit > 1);
+         a.Cout == 128 && a.Kpad == 9 * a.Cin && a.Cin % 32 == 0 && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0 && a.wpk != nullptr && !(a.splitk && a.ksplit > 1);
 }
 
 int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {

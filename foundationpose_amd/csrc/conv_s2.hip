@@ -50,7 +50,8 @@ struct S2Cfg {
 
 // Fragment order: [cout block][wave 4][chunk Cin/16][tap 9][co tile CT][lane 64][8 halfs]; lane (lr, lh) of a fragment holds
 // W[co = ((cb*4 + wave)*CT + ct)*32 + lr][k = tap*Cin + chunk*16 + lh*8 .. +8] of the [Cout][Kpad] image (K index = tap*Cin + ci).
-__global__ void s2_pack_kernel(const f16 *__restrict__ w, int Cin, int Kpad, int CT, size_t total, f16 *__restrict__ out) {
+// order 1 (conv_s1b.hip): [wave group][32-channel group][tap 9][16-channel half 2][co tile CT][lane][8 halfs]
+__global__ void s2_pack_kernel(const f16 *__restrict__ w, int Cin, int Kpad, int CT, size_t total, f16 *__restrict__ out, int order) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int e = idx & 7, lane = (idx >> 3) & 63;
@@ -58,10 +59,20 @@ __global__ void s2_pack_kernel(const f16 *__restrict__ w, int Cin, int Kpad, int
   const int nch = Cin / 16;
   const int ct = rest % CT;
   rest /= CT;
-  const int tap = rest % 9;
-  rest /= 9;
-  const int chunk = rest % nch;
-  rest /= nch;                                                          // = cb*4 + wave
+  int tap, chunk;
+  if (order == 1) {
+    const int ks = rest % 2;
+    rest /= 2;
+    tap = rest % 9;
+    rest /= 9;
+    chunk = (int)(rest % (nch / 2)) * 2 + ks;
+    rest /= nch / 2;
+  } else {
+    tap = rest % 9;
+    rest /= 9;
+    chunk = rest % nch;
+    rest /= nch;                                                        // = cb*4 + wave
+  }
   const int co = ((int)rest * CT + ct) * 32 + (lane & 31);
   const int k = tap * Cin + chunk * 16 + (lane >> 5) * 8 + e;
   out[idx] = w[(size_t)co * Kpad + k];
@@ -227,12 +238,12 @@ bool s2_supported(const ConvArgs &a) {
 
 size_t s2_packed_halfs(int Cout, int Cin) { return (size_t)Cout * 9 * Cin + 3 * 2 * 512; }    // + three taps of prefetch past the end
 
-int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s, int ct_force) {
+int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s, int ct_force, int order) {
   const int ct = ct_force ? ct_force : s2_ct_for(Cout);
-  FP_REQUIRE(ct != 0 && Cin % 16 == 0 && Kpad >= 9 * Cin, "s2_pack_weights: unsupported layer");
+  FP_REQUIRE(ct != 0 && Cin % 16 == 0 && Kpad >= 9 * Cin && (order == 0 || Cin % 32 == 0), "s2_pack_weights: unsupported layer");
   const size_t total = (size_t)Cout * 9 * Cin;
   FP_CHECK_HIP(hipMemsetAsync(d_out + total, 0, (s2_packed_halfs(Cout, Cin) - total) * sizeof(f16), s));
-  hipLaunchKernelGGL(s2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_w, Cin, Kpad, ct, total, d_out);
+  hipLaunchKernelGGL(s2_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_w, Cin, Kpad, ct, total, d_out, order);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

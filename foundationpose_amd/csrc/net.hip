@@ -135,7 +135,7 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
     FP_CHECK_HIP(hipMalloc(&pk, s2_packed_halfs(Cout, CinP) * sizeof(f16)));
     net->allocs.push_back(pk);
     out->wpk = (f16 *)pk;
-    FP_TRY(s2_pack_weights(out->w, Cout, CinP, Kpad, out->wpk, nullptr, stride == 1 ? 2 : 0));      // (conv_s1b.hip: 64 couts per wave group)
+    FP_TRY(s2_pack_weights(out->w, Cout, CinP, Kpad, out->wpk, nullptr, stride == 1 ? 2 : 0, stride == 1 ? 1 : 0));      // (conv_s1b.hip: 64 couts per wave group)
     FP_CHECK_HIP(hipStreamSynchronize(nullptr));
   }
   return FP_OK;

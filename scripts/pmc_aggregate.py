@@ -63,7 +63,7 @@ def main():
     f.write('kernel,grid_threads,launches,FETCH_SIZE_KB_raw_mean,fetch_MB_corrected_x2,WRITE_SIZE_MB_mean\n')
     for r in rows:
       f.write('"%s",%s,%d,%.0f,%.1f,%.1f\n' % r)
-  halo = [r for r in rows if 'conv3x3_halo' in r[0]]
+  halo = [r for r in rows if 'conv3x3_halo' in r[0] or 'conv3x3_s1_band' in r[0]]      # the 3x3 stride-1 class: halo kernel + band kernel (C = 128)
   n = sum(r[2] for r in halo)
   fe = sum(r[4] * r[2] for r in halo) / n * 1e6
   wr = sum(r[5] * r[2] for r in halo) / n * 1e6

@@ -472,12 +472,12 @@ def test_to_device_moves_the_predictors(nets_gpu):
 
 
 def test_kernel_variants_reproduce_the_goldens():
-  """Kernel variants that an environment knob selects (read once per process, so each runs in ONE child process): the band form of the
-  128 -> 128 convolutions (FP_C128_BAND=1, conv_s1b.hip), the one-stream trunk and heads (FP_TRUNK_STREAMS=1, FP_HEADS_SERIAL=1).  Each
+  """Kernel variants that an environment knob selects (read once per process, so each runs in ONE child process): the 128 -> 128
+  convolutions on the general 3x3 kernel instead of the band form (FP_C128_BAND=0), the one-stream trunk and heads (FP_TRUNK_STREAMS=1, FP_HEADS_SERIAL=1).  Each
   must reproduce the reference modules' golden outputs under the same rules as the default build."""
   import os, subprocess, sys
   script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'check_kernel_variant.py')
-  for knobs in ({'FP_C128_BAND': '1'}, {'FP_TRUNK_STREAMS': '1', 'FP_HEADS_SERIAL': '1'}):
+  for knobs in ({'FP_C128_BAND': '0'}, {'FP_TRUNK_STREAMS': '1', 'FP_HEADS_SERIAL': '1'}):
     r = subprocess.run([sys.executable, script], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, f'{knobs}: {r.stdout[-1500:]}\n{r.stderr[-1500:]}'
     assert 'variant ok' in r.stdout
