@@ -74,7 +74,7 @@ _PROTOS = {
   'fp_refine_predict_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, POINTER(FpRefineCfg), c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_score_predict_features_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, c_double, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_score_predict_features': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, c_double, c_int, c_void_p, c_int, c_void_p, c_void_p]),
-  'fp_conv3x3_c128_band_f16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+  'fp_conv3x3_band_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_conv2d_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
   'fp_token_linear_f16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_head_mlp_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_void_p, c_void_p]),

@@ -732,11 +732,12 @@ extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int
   return launch_conv(ctx, a, (hipStream_t)stream);
 }
 
-// Building block for the parity tests: the band-in-LDS form of the 128 -> 128 3x3 stride-1 layers on 40x40 maps (conv_s1b.hip), which
-// the networks use for batches of >= 8 hypotheses; same operands as fp_conv2d_f16 (w_packed [128][1152] fp16).
-extern "C" int fp_conv3x3_c128_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, const void *d_w_packed, const float *d_bias, const void *d_res,
-                                        int relu, void *d_out, void *stream) {
-  FP_REQUIRE(ctx && d_in && d_w_packed && d_bias && d_out && Nimg >= 0, "fp_conv3x3_c128_band_f16: bad argument");
+// Building block for the parity tests: the band-in-LDS form of the C -> C 3x3 stride-1 layers on 40x40 maps (conv_s1b.hip; C = 128 or 256),
+// which the networks use for batches of >= 8 hypotheses; same operands as fp_conv2d_f16 (w_packed [C][9 C] fp16).
+extern "C" int fp_conv3x3_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, int C, const void *d_w_packed, const float *d_bias, const void *d_res,
+                                   int relu, void *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_in && d_w_packed && d_bias && d_out && Nimg >= 0, "fp_conv3x3_band_f16: bad argument");
+  FP_REQUIRE(C == 128 || C == 256, "fp_conv3x3_band_f16: C=%d (128 or 256)", C);
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.in = (const f16 *)d_in;
@@ -746,23 +747,23 @@ extern "C" int fp_conv3x3_c128_band_f16(fp_ctx *ctx, const void *d_in, int Nimg,
   a.out = d_out;
   a.Nimg = Nimg;
   a.H = a.W = a.Ho = a.Wo = 40;
-  a.Cin = a.Cout = 128;
+  a.Cin = a.Cout = C;
   a.KH = a.KW = 3;
   a.stride = 1;
   a.pad = 1;
-  a.Kpad = 9 * 128;
+  a.Kpad = 9 * C;
   a.M = Nimg * 1600;
   a.relu = relu;
-  a.out_ld = 128;
+  a.out_ld = C;
   a.split_m = 0x7fffffff;
   a.post_period = 1;
   a.tokens = 400;
   if (a.M == 0) return FP_OK;
-  const size_t bytes = s2_packed_halfs(128, 128) * sizeof(f16);
+  const size_t bytes = s2_packed_halfs(C, C) * sizeof(f16);
   FP_TRY(fp_arena_ensure(ctx, bytes + 4096));
   const size_t mark = ctx->arena.off;
   f16 *pk = (f16 *)ctx->arena.take(bytes);
-  int rc = pk ? s2_pack_weights(a.w, 128, 128, a.Kpad, pk, (hipStream_t)stream, 2, 1) : FP_ENOMEM;
+  int rc = pk ? s2_pack_weights(a.w, C, C, a.Kpad, pk, (hipStream_t)stream, 2, 1) : FP_ENOMEM;
   a.wpk = pk;
   if (rc == FP_OK) rc = launch_conv_s1b(ctx, a, (hipStream_t)stream);
   ctx->arena.off = mark;

@@ -469,8 +469,8 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const char *cls = halo ? "conv3x3_halo" : (a.KW == 3) ? "conv3x3_s2" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
   {
-    static const bool band128 = !(getenv("FP_C128_BAND") && atoi(getenv("FP_C128_BAND")) == 0);   // conv_s1b.hip (bit-identical to the halo kernel); FP_C128_BAND=0: off
-    if (band128 && a.Nimg >= 16 && s1b_supported(a)) return launch_conv_s1b(ctx, a, s);
+    static const int band = getenv("FP_C128_BAND") ? atoi(getenv("FP_C128_BAND")) : 1;   // conv_s1b.hip (bit-identical to the halo kernel); 0: off, 2: also the 256 -> 256 layers
+    if (band != 0 && (a.Cin == 128 || band == 2) && a.Nimg >= 16 && s1b_supported(a)) return launch_conv_s1b(ctx, a, s);
   }
   if (halo) return launch_conv_halo(a, s);
   if (stem_supported(a)) return launch_stem(ctx, a, s);

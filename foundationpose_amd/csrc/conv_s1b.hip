@@ -1,14 +1,15 @@
-// 3x3 / stride-1 / pad-1 convolution 128 -> 128 on 40x40 maps (the four ResnetBasicBlock convolutions of encodeA / encoderA,
-// network_modules.py:73-111 via refine_network.py:39-40) on the structure of conv_s2.hip instead of conv_halo.hip.
+// 3x3 / stride-1 / pad-1 convolutions on 40x40 maps - 128 -> 128 (the four ResnetBasicBlock convolutions of encodeA / encoderA) and
+// 256 -> 256 (those of encodeAB's first stage; network_modules.py:73-111 via refine_network.py:39-47) - on the structure of conv_s2.hip
+// instead of conv_halo.hip.
 // Bit-identical to conv3x3_halo_dma_kernel<40>: an output element accumulates in the same order - 32-channel groups, inside a group
 // kernel row by kernel row, inside a row tap by tap, inside a tap the two 16-channel MFMA steps - from the same bias, and the epilogue
-// rounds once after the same fp32 residual add (tests/test_gpu_kernels.py::test_c128_band_kernel_equals_halo_kernel).  Full-batch launches
+// rounds once after the same fp32 residual add (tests/test_gpu_kernels.py::test_band_kernel_equals_halo_kernel).  Full-batch launches
 // (504 images, kernel trace, first form with 16-channel chunks): 215 / 242 us without / with residual against 223 / 247 us.
 //
 // With four K chunks of 32 channels the 8-wave halo kernel spends 39 % of a workgroup's life in prologue and epilogue, one workgroup
 // per CU.  Here
-//   * a workgroup (4 waves) owns 8 output rows x 40 = 320 pixels of ONE image (5 tiles per image: no tile straddles two) x all 128
-//     output channels: wave (c, p) owns 64 couts (2 accumulator tiles) x the 160 pixels of rows 4p .. 4p+3 (5 pixel tiles of 32);
+//   * a workgroup (4 waves) owns 8 output rows x 40 = 320 pixels of ONE image (5 tiles per image: no tile straddles two) x a block of
+//     128 output channels (the blocks of a pixel tile are neighbours in the grid: they share the band in L2): wave (c, p) owns 64 couts (2 accumulator tiles) x the 160 pixels of rows 4p .. 4p+3 (5 pixel tiles of 32);
 //   * per 32-channel group the band goes to LDS once by LDS-DMA as two 16-channel planes (10 input rows x 42 columns of 32-byte
 //     pixels each, row pitch 56 slots: 56 = 40 (mod 16) keeps the lane -> bank map of a 32-pixel tile unchanged across its row breaks;
 //     the two 16-byte halves of slot q swapped when bit 3 of q is set), double buffered (72 KB), and feeds all 9 taps of both planes;
@@ -17,7 +18,10 @@
 //   * two workgroups per CU (<= 256 VGPRs each).
 // Epilogue: accumulators start at the folded BN bias; residual rows staged through LDS and added in fp32, ReLU, one rounding to fp16,
 // 16-byte NHWC stores (with the channel-concat addressing of the last encodeA layer: out_ld / split_m / coff_hi).
-// FP_C128_BAND=0 sends these layers back to the halo kernel.
+// Default for the 128 -> 128 layers (FP_C128_BAND=0 sends them back to the halo kernel).  The 256 -> 256 layers take it with FP_C128_BAND=2
+// only: bit-identical too, but in an alternating A/B of the bench step 35.54 / 35.66 / 35.60 ms against 35.50 / 35.54 / 35.57 - with
+// eight K groups the halo kernel's prologue / epilogue share is small and its weights are shared through LDS (here each cout block
+// re-reads the band and each wave streams its own weights).
 #include "common.h"
 
 #define B1_THREADS 256
@@ -39,7 +43,8 @@ __device__ __forceinline__ void b1_glds16(const void *g, unsigned lds_addr) {
 }
 
 template <bool RES>
-__global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs p, const f16 *__restrict__ wpk, const f16 *__restrict__ zero_page, int n_tiles) {
+__global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs p, const f16 *__restrict__ wpk, const f16 *__restrict__ zero_page, int n_tiles,
+                                                                        int n_cob) {
   constexpr int W = B1_W, H = B1_W, P = B1_P, NPT = B1_NPT, DPW = B1_DPW, CT = 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char b1_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,7 +52,8 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
   const int ch = wave & 1, ph = wave >> 1;                 // cout half, pixel half
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void *)b1_smem;
   const int tile = xcd_remap(blockIdx.x, n_tiles);
-  const int img = tile / (H / B1_ROWS), oy0 = (tile - img * (H / B1_ROWS)) * B1_ROWS;
+  const int cob = tile % n_cob, pt = tile / n_cob;          // 128-cout block, pixel tile
+  const int img = pt / (H / B1_ROWS), oy0 = (pt - img * (H / B1_ROWS)) * B1_ROWS;
   const int ngrp = p.Cin >> 5;                             // 32-channel groups
 
   // ---- band DMA: instruction u = wave + 4 v, lane l -> slot 32 u + l/2 of the group's 1120 (plane ks = slot / 560, slot q of the plane),
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
     qb[j] = (((4 * ph + jr) * P + ox) << 5) | (lh << 4);
   }
   // ---- A fragments: this wave's stream of 1-KB fragments, (group, tap, 16-channel half, co tile) in order (s2_pack_weights order 1) ----
-  const half8 *wp = reinterpret_cast<const half8 *>(wpk) + ((size_t)ch * ngrp * 18 * CT) * 64 + lane;
+  const half8 *wp = reinterpret_cast<const half8 *>(wpk) + ((size_t)(cob * 2 + ch) * ngrp * 18 * CT) * 64 + lane;
   half8 aq[3][CT];
   int f = 0;
   auto a_fetch = [&](int slot) __attribute__((always_inline)) {
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
 
   floatx16 acc[CT][NPT];
   {
-    const int co0 = ch * 64;
+    const int co0 = cob * 128 + ch * 64;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
   f16 *stage = reinterpret_cast<f16 *>(b1_smem) + (size_t)wave * (32 * B1_STAGE_LD);
   const float lo = p.relu ? 0.f : -__builtin_inff();
   const int m_wave = (img * H + oy0 + 4 * ph) * W;        // first output pixel of this wave (flattened over images)
-  const int co0 = ch * 64;
+  const int co0 = cob * 128 + ch * 64;
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
     if constexpr (RES) {
@@ -192,26 +198,26 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
 }
 
 bool s1b_supported(const ConvArgs &a) {
-  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.out_mode == 0 && !a.post_add && a.H == B1_W && a.W == B1_W && a.Cin == 128 &&
-         a.Cout == 128 && a.Kpad == 9 * a.Cin && a.Cin % 32 == 0 && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0 && a.wpk != nullptr && !(a.splitk && a.ksplit > 1);
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.out_mode == 0 && !a.post_add && a.H == B1_W && a.W == B1_W && a.Cin % 32 == 0 &&
+         a.Cout % 128 == 0 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0 && a.wpk != nullptr && !(a.splitk && a.ksplit > 1);
 }
 
 int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   FP_REQUIRE(s1b_supported(a), "launch_conv_s1b: unsupported layer");
   static bool set0 = false, set1 = false;
-  const int n_tiles = a.Nimg * (B1_W / B1_ROWS);
+  const int n_cob = a.Cout / 128, n_tiles = a.Nimg * (B1_W / B1_ROWS) * n_cob;
   if (a.res) {
     if (!set1) {
       FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_s1_band_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES));
       set1 = true;
     }
-    hipLaunchKernelGGL(conv3x3_s1_band_kernel<true>, dim3(n_tiles), dim3(B1_THREADS), B1_LDS_BYTES, s, a, a.wpk, (const f16 *)ctx->zero_page, n_tiles);
+    hipLaunchKernelGGL(conv3x3_s1_band_kernel<true>, dim3(n_tiles), dim3(B1_THREADS), B1_LDS_BYTES, s, a, a.wpk, (const f16 *)ctx->zero_page, n_tiles, n_cob);
   } else {
     if (!set0) {
       FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_s1_band_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES));
       set0 = true;
     }
-    hipLaunchKernelGGL(conv3x3_s1_band_kernel<false>, dim3(n_tiles), dim3(B1_THREADS), B1_LDS_BYTES, s, a, a.wpk, (const f16 *)ctx->zero_page, n_tiles);
+    hipLaunchKernelGGL(conv3x3_s1_band_kernel<false>, dim3(n_tiles), dim3(B1_THREADS), B1_LDS_BYTES, s, a, a.wpk, (const f16 *)ctx->zero_page, n_tiles, n_cob);
   }
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;

@@ -129,8 +129,8 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
   out->stride = stride;
   FP_TRY(upload(net, hw, &out->w));
   FP_TRY(upload(net, hb, &out->bias));
-  // fragment-ordered copy for the band kernels: the 3x3 stride-2 layers (conv_s2.hip) and the 128 -> 128 stride-1 layers (conv_s1b.hip)
-  if (K == 3 && (stride == 2 || (stride == 1 && CinP == 128 && Cout == 128)) && CinP % 16 == 0 && s2_ct_for(Cout) != 0) {
+  // fragment-ordered copy for the band kernels: the 3x3 stride-2 layers (conv_s2.hip) and the 128 -> 128 / 256 -> 256 stride-1 layers, which run on 40x40 maps (conv_s1b.hip)
+  if (K == 3 && (stride == 2 || (stride == 1 && CinP == Cout && (Cout == 128 || Cout == 256))) && CinP % 16 == 0 && s2_ct_for(Cout) != 0) {
     void *pk = nullptr;
     FP_CHECK_HIP(hipMalloc(&pk, s2_packed_halfs(Cout, CinP) * sizeof(f16)));
     net->allocs.push_back(pk);

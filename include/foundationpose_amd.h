@@ -201,11 +201,12 @@ int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin
                   int Cout, int KH, int KW, int stride, int pad, const void *d_res, int relu, void *d_out, int out_f32,
                   void *stream);
 
-/* The band-in-LDS form of the 128 -> 128 3x3 stride-1 / pad-1 convolutions on 40x40 maps (csrc/conv_s1b.hip; ResnetBasicBlock convolutions
- * of encodeA, learning/models/network_modules.py:73-111): what the networks run for batches of >= 8 hypotheses.  Same operands as
- * fp_conv2d_f16 (w_packed [128][1152]); bit-identical to the general 3x3 stride-1 kernel behind fp_conv2d_f16. */
-int fp_conv3x3_c128_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, const void *d_w_packed, const float *d_bias, const void *d_res,
-                             int relu, void *d_out, void *stream);
+/* The band-in-LDS form of the C -> C (C = 128 | 256) 3x3 stride-1 / pad-1 convolutions on 40x40 maps (csrc/conv_s1b.hip; the
+ * ResnetBasicBlock convolutions of encodeA and of encodeAB's first stage, learning/models/network_modules.py:73-111): what the networks
+ * run for batches of >= 8 hypotheses.  Same operands as fp_conv2d_f16 (w_packed [C][9 C]); bit-identical to the general 3x3 stride-1
+ * kernel behind fp_conv2d_f16. */
+int fp_conv3x3_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, int C, const void *d_w_packed, const float *d_bias, const void *d_res,
+                        int relu, void *d_out, void *stream);
 /* fused multi-head self-attention core, 4 heads x 128: qk [M][1024] fp16 (q|k), vt [B][4][128][416] fp16 -> out [M][512] fp16.
  * vt is V transposed, token t of a hypothesis in column (t & ~15) | ((t>>2 & 1) << 3) | ((t>>3 & 1) << 2) | (t & 3)
  * (tokens of a group of 16 in the order 0-3, 8-11, 4-7, 12-15); columns of tokens >= T must hold zeros. */

@@ -385,26 +385,28 @@ def test_conv_igemm_vs_fp32_reference(fp, shape):
     assert err <= (2e-3 if not out_f32 else 2e-4) * scale + 1e-5, f'out_f32={out_f32}: err {err:.3e} scale {scale:.2f}'
 
 
-@pytest.mark.parametrize('N,use_res,relu', [(20, False, True), (20, True, True), (37, True, False), (504, True, True)])
-def test_c128_band_kernel_equals_halo_kernel(fp, N, use_res, relu):
-  """The band-in-LDS form of the 128 -> 128 layers (conv_s1b.hip, what the networks run for >= 8 hypotheses) accumulates every output
-  element in the order of the general 3x3 stride-1 kernel (32-channel groups, kernel rows, taps, two 16-channel steps) from the same
-  bias and rounds once behind the same fp32 residual add: BIT-identical outputs, and within the fp32 reference's tolerance."""
+@pytest.mark.parametrize('N,C,use_res,relu', [(20, 128, False, True), (20, 128, True, True), (37, 128, True, False), (504, 128, True, True),
+                                              (18, 256, False, True), (21, 256, True, True), (252, 256, True, True)])
+def test_band_kernel_equals_halo_kernel(fp, N, C, use_res, relu):
+  """The band-in-LDS form of the 128 -> 128 and 256 -> 256 layers on 40x40 maps (conv_s1b.hip, what the networks run for >= 8
+  hypotheses) accumulates every output element in the order of the general 3x3 stride-1 kernel (32-channel groups, kernel rows, taps, two
+  16-channel steps) from the same bias and rounds once behind the same fp32 residual add: BIT-identical outputs, and within the fp32
+  reference's tolerance."""
   from foundationpose_amd._lib import check, lib, ptr, stream_ptr
-  g = torch.Generator(device='cuda').manual_seed(1000 + N)
-  x = torch.randn((N, 40, 40, 128), device='cuda', generator=g).half()
+  g = torch.Generator(device='cuda').manual_seed(1000 + N + C)
+  x = torch.randn((N, 40, 40, C), device='cuda', generator=g).half()
   x[:, :, :, ::3] = x[:, :, :, ::3].relu()                       # some exact zeros, as behind a ReLU
-  w = (torch.randn((128, 128, 3, 3), device='cuda', generator=g) * (2.0 / (128 * 9)) ** 0.5).half()
-  b = torch.randn((128,), device='cuda', generator=g) * 0.1
-  res = torch.randn((N, 40, 40, 128), device='cuda', generator=g).half() if use_res else None
-  wp = _pack_conv_weight(w.float().cpu(), 128).cuda()
+  w = (torch.randn((C, C, 3, 3), device='cuda', generator=g) * (2.0 / (C * 9)) ** 0.5).half()
+  b = torch.randn((C,), device='cuda', generator=g) * 0.1
+  res = torch.randn((N, 40, 40, C), device='cuda', generator=g).half() if use_res else None
+  wp = _pack_conv_weight(w.float().cpu(), C).cuda()
   outs = []
   for band in (0, 1):
-    out = torch.full((N, 40, 40, 128), float('nan'), dtype=torch.float16, device='cuda')
+    out = torch.full((N, 40, 40, C), float('nan'), dtype=torch.float16, device='cuda')
     if band:
-      check(lib().fp_conv3x3_c128_band_f16(fp['ctx'].handle, ptr(x), N, ptr(wp), ptr(b), ptr(res) if use_res else None, 1 if relu else 0, ptr(out), stream_ptr()))
+      check(lib().fp_conv3x3_band_f16(fp['ctx'].handle, ptr(x), N, C, ptr(wp), ptr(b), ptr(res) if use_res else None, 1 if relu else 0, ptr(out), stream_ptr()))
     else:
-      check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(x), N, 40, 40, 128, ptr(wp), ptr(b), 128, 3, 3, 1, 1, ptr(res) if use_res else None,
+      check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(x), N, 40, 40, C, ptr(wp), ptr(b), C, 3, 3, 1, 1, ptr(res) if use_res else None,
                                 1 if relu else 0, ptr(out), 0, stream_ptr()))
     outs.append(out)
   torch.cuda.synchronize()
