@@ -733,7 +733,7 @@ extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int
 }
 
 // Building block for the parity tests: the band-in-LDS form of the C -> C 3x3 stride-1 layers on 40x40 maps (conv_s1b.hip; C = 128 or 256),
-// which the networks use for batches of >= 8 hypotheses; same operands as fp_conv2d_f16 (w_packed [C][9 C] fp16).
+// which the networks use for batches of more than 40 hypotheses (more than one round of the general kernel's tiles); same operands as fp_conv2d_f16 (w_packed [C][9 C] fp16).
 extern "C" int fp_conv3x3_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, int C, const void *d_w_packed, const float *d_bias, const void *d_res,
                                    int relu, void *d_out, void *stream) {
   FP_REQUIRE(ctx && d_in && d_w_packed && d_bias && d_out && Nimg >= 0, "fp_conv3x3_band_f16: bad argument");

@@ -470,7 +470,9 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   ProfScope ps(ctx, s, cls, flops);
   {
     static const int band = getenv("FP_C128_BAND") ? atoi(getenv("FP_C128_BAND")) : 1;   // conv_s1b.hip (bit-identical to the halo kernel); 0: off, 2: also the 256 -> 256 layers
-    if (band != 0 && (a.Cin == 128 || band == 2) && a.Nimg >= 16 && s1b_supported(a)) return launch_conv_s1b(ctx, a, s);
+    // ... from the batch size on at which the general kernel needs more than one round of its 512-pixel tiles (82 images on 256 CUs): below,
+    // one round of those is faster (32 hypotheses per GPU: 6.67 against 6.79 ms per step; 63: 10.24 against 10.13)
+    if (band != 0 && (a.Cin == 128 || band == 2) && (long long)a.M > (long long)ctx->num_cu * 512 && s1b_supported(a)) return launch_conv_s1b(ctx, a, s);
   }
   if (halo) return launch_conv_halo(a, s);
   if (stem_supported(a)) return launch_stem(ctx, a, s);

@@ -203,7 +203,7 @@ int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin
 
 /* The band-in-LDS form of the C -> C (C = 128 | 256) 3x3 stride-1 / pad-1 convolutions on 40x40 maps (csrc/conv_s1b.hip; the
  * ResnetBasicBlock convolutions of encodeA and of encodeAB's first stage, learning/models/network_modules.py:73-111): what the networks
- * run for batches of >= 8 hypotheses.  Same operands as fp_conv2d_f16 (w_packed [C][9 C]); bit-identical to the general 3x3 stride-1
+ * run for batches of more than 40 hypotheses (more than one round of the general kernel's tiles).  Same operands as fp_conv2d_f16 (w_packed [C][9 C]); bit-identical to the general 3x3 stride-1
  * kernel behind fp_conv2d_f16. */
 int fp_conv3x3_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, int C, const void *d_w_packed, const float *d_bias, const void *d_res,
                         int relu, void *d_out, void *stream);

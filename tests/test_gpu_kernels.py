@@ -388,7 +388,7 @@ def test_conv_igemm_vs_fp32_reference(fp, shape):
 @pytest.mark.parametrize('N,C,use_res,relu', [(20, 128, False, True), (20, 128, True, True), (37, 128, True, False), (504, 128, True, True),
                                               (18, 256, False, True), (21, 256, True, True), (252, 256, True, True)])
 def test_band_kernel_equals_halo_kernel(fp, N, C, use_res, relu):
-  """The band-in-LDS form of the 128 -> 128 and 256 -> 256 layers on 40x40 maps (conv_s1b.hip, what the networks run for >= 8
+  """The band-in-LDS form of the 128 -> 128 and 256 -> 256 layers on 40x40 maps (conv_s1b.hip, what the networks run for > 40
   hypotheses) accumulates every output element in the order of the general 3x3 stride-1 kernel (32-channel groups, kernel rows, taps, two
   16-channel steps) from the same bias and rounds once behind the same fp32 residual add: BIT-identical outputs, and within the fp32
   reference's tolerance."""
