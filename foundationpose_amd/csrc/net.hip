@@ -410,7 +410,7 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
 int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0, int NT, int N, f16 **tokens_out, hipStream_t s) {
   static const int n_streams = getenv("FP_TRUNK_STREAMS") ? atoi(getenv("FP_TRUNK_STREAMS")) : 2;
   const size_t img = (size_t)160 * 160 * 8;
-  static const int n_min = getenv("FP_TRUNK_MIN") ? atoi(getenv("FP_TRUNK_MIN")) : 64;
+  static const int n_min = getenv("FP_TRUNK_MIN") ? atoi(getenv("FP_TRUNK_MIN")) : 96;       // (64 hypotheses - a tracking frame - run 1 % faster as one batch: 5.60 - 5.65 against 5.70 - 5.77 ms)
   if (n_streams < 2 || N < n_min) return run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, tokens_out, s);
   TAKE(tok, f16, (size_t)N * 400 * 512);
   const int n_parts = std::min(n_streams, std::min(fp_ctx::NSIDE, std::max(2, N / 32)));
