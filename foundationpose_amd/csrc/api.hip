@@ -60,6 +60,16 @@ int fp_arena_ensure(fp_ctx *ctx, size_t bytes) {
 
 extern int g_halo_tail, g_halo_npw, g_halo_form;
 
+int fp_set_kernel_attributes(fp_ctx *ctx) {
+  std::vector<KernelLds> v;
+  conv_kernel_lds(v), conv_halo_kernel_lds(v), conv_s1b_kernel_lds(v), conv_s2_kernel_lds(v), stem_kernel_lds(v);
+  tok_gemm_kernel_lds(v), head_mlp_kernel_lds(v), attn_kernel_lds(v), raster_kernel_lds(v);
+  FP_CHECK_HIP(hipSetDevice(ctx->device));
+  for (const KernelLds &k : v)
+    if (k.bytes > 48 * 1024) FP_CHECK_HIP(hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes));
+  return FP_OK;
+}
+
 extern "C" int fp_ctx_create(int device, fp_ctx **out) {
   FP_REQUIRE(out, "fp_ctx_create: null out");
   if (const char *e = getenv("FP_HALO_TAIL")) g_halo_tail = atoi(e) != 0;
@@ -78,6 +88,12 @@ extern "C" int fp_ctx_create(int device, fp_ctx **out) {
     delete c;
     fp_set_error("fp_ctx_create: zero page allocation failed");
     return FP_ENOMEM;
+  }
+  const int rc = fp_set_kernel_attributes(c);      // per device: every kernel of the library that needs more than 64 KB of LDS
+  if (rc != FP_OK) {
+    (void)hipFree(c->zero_page);
+    delete c;
+    return rc;
   }
   *out = c;
   return FP_OK;

@@ -387,14 +387,11 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
 #endif
 }
 
+void attn_kernel_lds(std::vector<KernelLds> &v) { v.push_back({(const void *)attention_kernel, (int)FA_LDS_BYTES}); }
+
 int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s) {
   FP_REQUIRE(T > 0 && T <= AT_MAXT, "attention: T=%d must be in [1,%d]", T, AT_MAXT);
   if (B == 0) return FP_OK;
-  static bool attr_set = false;       // once: not a stream operation (and not wanted inside a graph capture)
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FA_LDS_BYTES));
-    attr_set = true;
-  }
   const int n_items = ((T + FA_QB - 1) / FA_QB) * 4 * B;
   const int grid = n_items < ctx->num_cu ? n_items : ctx->num_cu;        // one persistent workgroup per CU (152 KB of LDS each)
   ProfScope ps(ctx, s, "attention", 4.0 * B * 4 * (double)T * T * AT_DH);

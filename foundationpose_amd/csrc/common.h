@@ -192,6 +192,25 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
 }
 #endif
 
+// Kernels that need more dynamic LDS than the 64-KB default carry hipFuncAttributeMaxDynamicSharedMemorySize.  The attribute belongs to
+// the function ON ONE DEVICE, so it is set for every such kernel of the library when a context is created on its device
+// (fp_ctx_create -> fp_set_kernel_attributes), not lazily behind process-wide flags: a second device in one process, a graph capture
+// and concurrent first launches from two threads all find the attributes in place.  Each .hip file lists its own kernels.
+struct KernelLds {
+  const void *fn;
+  int bytes;
+};
+void conv_kernel_lds(std::vector<KernelLds> &v);        // conv.hip
+void conv_halo_kernel_lds(std::vector<KernelLds> &v);   // conv_halo.hip
+void conv_s1b_kernel_lds(std::vector<KernelLds> &v);    // conv_s1b.hip
+void conv_s2_kernel_lds(std::vector<KernelLds> &v);     // conv_s2.hip
+void stem_kernel_lds(std::vector<KernelLds> &v);        // stem.hip
+void tok_gemm_kernel_lds(std::vector<KernelLds> &v);    // tok_gemm.hip
+void head_mlp_kernel_lds(std::vector<KernelLds> &v);    // head_mlp.hip
+void attn_kernel_lds(std::vector<KernelLds> &v);        // attn.hip
+void raster_kernel_lds(std::vector<KernelLds> &v);      // raster.hip
+int fp_set_kernel_attributes(fp_ctx *ctx);              // api.hip: all of the above on ctx->device
+
 // ---- kernel launchers implemented in the .hip files ----
 struct ConvArgs {
   const f16 *in;

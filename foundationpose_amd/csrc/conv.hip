@@ -427,18 +427,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
 
 void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4);      // conv_halo.hip: main / quarter-tile split
 
+template <int BM>
+constexpr int igemm2_lds_bytes() {
+  constexpr int main_b = 3 * (C2_BN * C2_BK + BM * C2_BK) * 2, epi_b = C2_BN * (BM + 8) * 2;
+  return main_b > epi_b ? main_b : epi_b;
+}
+
+template <int BM, int KW, bool CIN8>
+static void igemm2_lds_both(std::vector<KernelLds> &v) {
+  v.push_back({(const void *)conv_igemm2_kernel<BM, KW, CIN8, true>, igemm2_lds_bytes<BM>()});
+  v.push_back({(const void *)conv_igemm2_kernel<BM, KW, CIN8, false>, igemm2_lds_bytes<BM>()});
+}
+
+void conv_kernel_lds(std::vector<KernelLds> &v) {       // every instantiation launch_conv can reach
+  igemm2_lds_both<128, 7, true>(v), igemm2_lds_both<64, 7, true>(v);
+  igemm2_lds_both<128, 3, false>(v), igemm2_lds_both<64, 3, false>(v);
+  igemm2_lds_both<128, 1, false>(v), igemm2_lds_both<64, 1, false>(v);
+}
+
 template <int BM, int KW, bool CIN8, bool RES>
 static int launch_two_r(fp_ctx *ctx, const ConvArgs &a, const f16 *zero_page, hipStream_t s) {
   const int n_tiles = ((a.M + C2_BN - 1) / C2_BN) * (a.Cout / BM);
   int n_main, n_tail4;
   halo_split(n_tiles, 2 * ctx->num_cu, &n_main, &n_tail4);
-  constexpr int main_b = 3 * (C2_BN * C2_BK + BM * C2_BK) * 2, epi_b = C2_BN * (BM + 8) * 2;
-  constexpr int lds = main_b > epi_b ? main_b : epi_b;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv_igemm2_kernel<BM, KW, CIN8, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
+  constexpr int lds = igemm2_lds_bytes<BM>();
   FP_REQUIRE(a.out_mode != 0 || (a.out_ld % 8 == 0 && a.coff_hi % 8 == 0), "conv: out_ld/coff must be multiples of 8 for fp16 output");
   hipLaunchKernelGGL((conv_igemm2_kernel<BM, KW, CIN8, RES>), dim3(n_main + n_tail4), dim3(256), lds, s, a, zero_page, n_main);
   FP_CHECK_HIP(hipGetLastError());
@@ -452,7 +464,7 @@ static int launch_two(fp_ctx *ctx, const ConvArgs &a, const f16 *zero_page, hipS
 }
 
 bool conv_halo_supported(const ConvArgs &a);
-int launch_conv_halo(const ConvArgs &a, hipStream_t s);
+int launch_conv_halo(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 bool stem_supported(const ConvArgs &a);                     // stem.hip
 int launch_stem(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
@@ -474,7 +486,7 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
     // one round of those is faster (32 hypotheses per GPU: 6.67 against 6.79 ms per step; 63: 10.24 against 10.13)
     if (band != 0 && (a.Cin == 128 || band == 2) && (long long)a.M > (long long)ctx->num_cu * 512 && s1b_supported(a)) return launch_conv_s1b(ctx, a, s);
   }
-  if (halo) return launch_conv_halo(a, s);
+  if (halo) return launch_conv_halo(ctx, a, s);
   if (stem_supported(a)) return launch_stem(ctx, a, s);
   if (a.wpk && a.M >= S2_MIN_PIXELS && s2_supported(a)) return launch_conv_s2(ctx, a, s);
   const bool bm128 = (a.Cout % 128 == 0);

@@ -228,7 +228,7 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
       // 6 steps (kx, k-step) x NT pixel tiles = 6 NT tile visits, 2 MFMAs each; pixel fragments rotate through BD registers
       // (the fragment of visit t+BD is requested right after the MFMAs of visit t), weight fragments of step st+1 go to the
       // spare set at the start of step st.  A tap's swizzle term is the same for all tiles of a step (tiles are 32 px apart).
-      constexpr int NV = 6 * NT, BD = NT >= 4 ? 4 : 2;
+      constexpr int NV = 6 * NT, BD = NT >= 4 ? 4 : (NT == 3 ? 3 : 2);
       half8 af[2][2], bf[BD];
       int tapb[3][2];                      // half offset of (tap pixel, channel group ks*2 + lh) of tile 0
 #pragma unroll
@@ -276,9 +276,9 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
         __builtin_amdgcn_sched_barrier(0);
       };
 #define V4(a) visit(IC<(a) < NV ? (a) : NV - 1>{}); if constexpr ((a) + 1 < NV) visit(IC<(a) + 1 < NV ? (a) + 1 : NV - 1>{}); if constexpr ((a) + 2 < NV) visit(IC<(a) + 2 < NV ? (a) + 2 : NV - 1>{}); if constexpr ((a) + 3 < NV) visit(IC<(a) + 3 < NV ? (a) + 3 : NV - 1>{});
-      V4(0) if constexpr (NV > 4) { V4(4) } if constexpr (NV > 8) { V4(8) V4(12) V4(16) V4(20) }
+      V4(0) if constexpr (NV > 4) { V4(4) } if constexpr (NV > 8) { V4(8) } if constexpr (NV > 12) { V4(12) } if constexpr (NV > 16) { V4(16) } if constexpr (NV > 20) { V4(20) }
 #undef V4
-      static_assert(NV == 6 || NV == 24, "visit list covers NT = 1 and NT = 4");
+      static_assert(NV <= 24, "visit list covers NT = 1 .. 4");
       STAMP(t_body += __builtin_amdgcn_s_memtime() - tb;)
     }
   }
@@ -373,11 +373,13 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
     u32x4 ov[OB];
 #pragma unroll
     for (int u = 0; u < OB; ++u) {
+      if (i0 + u >= NOUT) break;                 // (NOUT = 12 for the 384-pixel tile: the second batch is half full)
       const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
       ov[u] = *reinterpret_cast<const u32x4 *>(&stage[px * HL_SLD + c16 * 8]);
     }
 #pragma unroll
     for (int u = 0; u < OB; ++u) {
+      if (i0 + u >= NOUT) break;
       const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
       const int m = m0 + px;
       if (m < p.M) {
@@ -401,8 +403,10 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
 #undef HALO_DIAG_SECTION
 #endif
 
+// Grid = n_main workgroups of 512 px x 128 co (whole rounds), then the rest of the pixels as tiles of nt_tail x 128 px (halo_plan):
+// what is less than a round of 512-pixel tiles is cut so that it fills the chip once.  A pixel's arithmetic does not depend on its tile.
 template <int W, bool RES, bool POST>
-__global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, int n_main, int tile0) {
+__global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, int n_main, int tile0, int nt_tail) {
   extern __shared__ __attribute__((aligned(16))) f16 lds[];
   constexpr int TMM = 512;
   const int n_ct = p.Cout / HL_BM;
@@ -412,10 +416,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, in
     halo_tile_dma<W, 4, RES, POST>(p, (L / n_ct) * TMM, (L % n_ct) * HL_BM, lds);
   } else {
     const int t = xcd_remap(blockIdx.x - n_main, gridDim.x - n_main);
-    const int L = tile0 + n_main + (t >> 2);
-    const int m0 = (L / n_ct) * TMM + (t & 3) * (TMM / 4);
+    const int m0 = ((tile0 + n_main) / n_ct) * TMM + (t / n_ct) * (nt_tail * 128), c0 = (t % n_ct) * HL_BM;
     if (m0 >= p.M) return;
-    halo_tile_dma<W, 1, RES, POST>(p, m0, (L % n_ct) * HL_BM, lds);
+    if (nt_tail == 1) halo_tile_dma<W, 1, RES, POST>(p, m0, c0, lds);
+    else if (nt_tail == 2) halo_tile_dma<W, 2, RES, POST>(p, m0, c0, lds);
+    else if (nt_tail == 3) halo_tile_dma<W, 3, RES, POST>(p, m0, c0, lds);
+    else halo_tile_dma<W, 4, RES, POST>(p, m0, c0, lds);
   }
 }
 
@@ -494,52 +500,79 @@ void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4) {
   }
 }
 
+// Tiling of a launch (M pixels, n_ct cout tiles of 128, `slots` CUs, one workgroup each): whole rounds of 512-pixel tiles, and what is
+// left - less than a round, or the whole of a small launch (a rank's shard of an 8-way job, a tracking frame) - as tiles of nt x 128
+// pixels, nt chosen for the shortest finish.  Relative cost of a tile by its nt (measured on one-round launches at C = 512: a round
+// of 128-pixel tiles lasts 0.43 of a round of 512-pixel ones - less operand reuse, the same prologue and epilogue).
+static const double kHaloTileCost[5] = {0.0, 0.43, 0.62, 0.81, 1.0};
+void halo_plan(int M, int n_ct, int slots, int *n_main, int *nt_tail, int *n_tail) {
+  const int qm = (M + 127) / 128;                       // 128-pixel quarters along the pixel axis
+  const int per_round = (slots / n_ct) * 4;             // quarters a round of 512-pixel tiles covers
+  int full = per_round > 0 ? qm / per_round : 0;
+  int rem = qm - full * per_round;
+  *n_main = full * (slots / n_ct) * n_ct;
+  *nt_tail = 4;
+  *n_tail = 0;
+  if (rem == 0) return;
+  if (!g_halo_tail) {                                   // FP_HALO_TAIL=0: 512-pixel tiles only
+    *n_tail = ((rem + 3) / 4) * n_ct;
+    return;
+  }
+  double best = 1e30;
+  for (int nt = 4; nt >= 1; --nt) {
+    const int wgs = ((rem + nt - 1) / nt) * n_ct;
+    const double cost = ((wgs + slots - 1) / slots) * kHaloTileCost[nt];
+    if (cost < best - 1e-9) {
+      best = cost;
+      *nt_tail = nt;
+      *n_tail = wgs;
+    }
+  }
+}
+
 #ifdef HALO_STAMP      // diagnostic builds only: entry points and launchers of the forms above
 #define HALO_DIAG_SECTION 3
 #include "diag/conv_halo_diag.inc"
 #undef HALO_DIAG_SECTION
 #endif
 
+template <int W>
+static void halo_lds_all(std::vector<KernelLds> &v) {
+  using C = HaloCfgD<W, 512>;
+  v.push_back({(const void *)conv3x3_halo_dma_kernel<W, false, false>, C::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_halo_dma_kernel<W, true, false>, C::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_halo_dma_kernel<W, false, true>, C::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_halo_dma_kernel<W, true, true>, C::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_halo_splitk_kernel<W>, HaloCfgD<W, 128>::LDS_BYTES});
+}
+void conv_halo_kernel_lds(std::vector<KernelLds> &v) { halo_lds_all<40>(v), halo_lds_all<20>(v); }
+
 template <int W, bool RES, bool POST>
-static int launch_halo_dma(const ConvArgs &a, hipStream_t s) {
+static int launch_halo_dma(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   using C = HaloCfgD<W, 512>;
   static_assert(HaloCfgD<W, 128>::LDS_BYTES <= C::LDS_BYTES, "tail tiles fit the main tile's LDS");
-  static bool attr_set = false;
-  static int slots = 256;
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_dma_kernel<W, RES, POST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    int dev = 0;
-    FP_CHECK_HIP(hipGetDevice(&dev));
-    FP_CHECK_HIP(hipDeviceGetAttribute(&slots, hipDeviceAttributeMultiprocessorCount, dev));
-    attr_set = true;
-  }
-  const int n_tiles = ((a.M + 511) / 512) * (a.Cout / HL_BM);
-  int n_main, n_tail4;
-  halo_split(n_tiles, slots, &n_main, &n_tail4);
+  const int slots = ctx->num_cu;
+  int n_main, nt_tail, n_tail;
+  halo_plan(a.M, a.Cout / HL_BM, slots, &n_main, &nt_tail, &n_tail);
   int tile0 = 0;
 #ifdef HALO_STAMP
   FP_TRY((diag_launch_persist<W, RES, POST>(a, slots, C::LDS_BYTES, &n_main, &tile0, s)));
 #endif
-  if (n_main + n_tail4 > 0)
-    hipLaunchKernelGGL((conv3x3_halo_dma_kernel<W, RES, POST>), dim3(n_main + n_tail4), dim3(512), C::LDS_BYTES, s, a, n_main, tile0);
+  if (n_main + n_tail > 0)
+    hipLaunchKernelGGL((conv3x3_halo_dma_kernel<W, RES, POST>), dim3(n_main + n_tail), dim3(512), C::LDS_BYTES, s, a, n_main, tile0, nt_tail);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
 
 template <int W>
-static int launch_halo_dma_flags(const ConvArgs &a, hipStream_t s) {
-  if (a.post_add) return a.res ? launch_halo_dma<W, true, true>(a, s) : launch_halo_dma<W, false, true>(a, s);
-  return a.res ? launch_halo_dma<W, true, false>(a, s) : launch_halo_dma<W, false, false>(a, s);
+static int launch_halo_dma_flags(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
+  if (a.post_add) return a.res ? launch_halo_dma<W, true, true>(ctx, a, s) : launch_halo_dma<W, false, true>(ctx, a, s);
+  return a.res ? launch_halo_dma<W, true, false>(ctx, a, s) : launch_halo_dma<W, false, false>(ctx, a, s);
 }
 
 template <int W>
 static int launch_halo_splitk(const ConvArgs &a, hipStream_t s) {
   using C = HaloCfgD<W, 128>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_halo_splitk_kernel<W>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
-  }
   const int n_q = ((a.M + 127) / 128) * (a.Cout / HL_BM);
   hipLaunchKernelGGL((conv3x3_halo_splitk_kernel<W>), dim3(n_q * a.ksplit), dim3(512), C::LDS_BYTES, s, a);
   hipLaunchKernelGGL(splitk_finish_kernel, dim3((a.M * (a.Cout / 4) + 255) / 256), dim3(256), 0, s, a);
@@ -558,7 +591,7 @@ int conv_halo_ksplit(const ConvArgs &a, int num_cu) {
   return k > 1 ? k : 0;
 }
 
-int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
+int launch_conv_halo(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   // lane offsets into the input tensor are 32-bit byte offsets from its base
   FP_REQUIRE((double)a.M * a.Cin * 2.0 < 4294967296.0, "conv3x3: input tensor of %.1f GB exceeds the 4 GB the kernel addresses", (double)a.M * a.Cin * 2e-9);
   if (a.splitk && a.ksplit > 1) {
@@ -571,5 +604,5 @@ int launch_conv_halo(const ConvArgs &a, hipStream_t s) {
     return a.W == 40 ? launch_halo_flags<40, 4>(a, s) : launch_halo_flags<20, 4>(a, s);
   }
 #endif
-  return a.W == 40 ? launch_halo_dma_flags<40>(a, s) : launch_halo_dma_flags<20>(a, s);
+  return a.W == 40 ? launch_halo_dma_flags<40>(ctx, a, s) : launch_halo_dma_flags<20>(ctx, a, s);
 }

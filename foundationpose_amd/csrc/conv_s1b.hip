@@ -202,21 +202,17 @@ bool s1b_supported(const ConvArgs &a) {
          a.Cout % 128 == 0 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0 && a.wpk != nullptr && !(a.splitk && a.ksplit > 1);
 }
 
+void conv_s1b_kernel_lds(std::vector<KernelLds> &v) {
+  v.push_back({(const void *)conv3x3_s1_band_kernel<true>, B1_LDS_BYTES});
+  v.push_back({(const void *)conv3x3_s1_band_kernel<false>, B1_LDS_BYTES});
+}
+
 int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   FP_REQUIRE(s1b_supported(a), "launch_conv_s1b: unsupported layer");
-  static bool set0 = false, set1 = false;
   const int n_cob = a.Cout / 128, n_tiles = a.Nimg * (B1_W / B1_ROWS) * n_cob;
   if (a.res) {
-    if (!set1) {
-      FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_s1_band_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES));
-      set1 = true;
-    }
     hipLaunchKernelGGL(conv3x3_s1_band_kernel<true>, dim3(n_tiles), dim3(B1_THREADS), B1_LDS_BYTES, s, a, a.wpk, (const f16 *)ctx->zero_page, n_tiles, n_cob);
   } else {
-    if (!set0) {
-      FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_s1_band_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B1_LDS_BYTES));
-      set0 = true;
-    }
     hipLaunchKernelGGL(conv3x3_s1_band_kernel<false>, dim3(n_tiles), dim3(B1_THREADS), B1_LDS_BYTES, s, a, a.wpk, (const f16 *)ctx->zero_page, n_tiles, n_cob);
   }
   FP_CHECK_HIP(hipGetLastError());

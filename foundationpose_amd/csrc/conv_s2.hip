@@ -251,16 +251,16 @@ int s2_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hip
 template <int WO, int ROWS, int CT>
 static int s2_launch(fp_ctx *ctx, const ConvArgs &a, const f16 *wpk, hipStream_t s) {
   using C = S2Cfg<WO, ROWS, CT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)conv3x3_s2_kernel<WO, ROWS, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    attr_set = true;
-  }
   const int rows = a.Nimg * WO, n_pt = (rows + ROWS - 1) / ROWS, n_cob = a.Cout / (128 * CT), n_tiles = n_pt * n_cob;
   hipLaunchKernelGGL((conv3x3_s2_kernel<WO, ROWS, CT>), dim3(n_tiles), dim3(S2_THREADS), C::LDS_BYTES, s, a, wpk, (const f16 *)ctx->zero_page, n_tiles,
                      n_cob);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
+}
+
+void conv_s2_kernel_lds(std::vector<KernelLds> &v) {
+  v.push_back({(const void *)conv3x3_s2_kernel<20, 8, 2>, S2Cfg<20, 8, 2>::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_s2_kernel<20, 8, 1>, S2Cfg<20, 8, 1>::LDS_BYTES});
 }
 
 int launch_conv_s2(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {

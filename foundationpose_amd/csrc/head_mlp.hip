@@ -251,16 +251,13 @@ __global__ __launch_bounds__(HM_THREADS, 1) void head_mlp_kernel(HeadMlpArgs p) 
       }
 }
 
+void head_mlp_kernel_lds(std::vector<KernelLds> &v) { v.push_back({(const void *)head_mlp_kernel, HM_LDS_BYTES}); }
+
 int launch_head_mlp(fp_ctx *ctx, const HeadMlpArgs &a, hipStream_t s) {
   FP_REQUIRE(a.att && a.tok && a.w_out && a.w1 && a.w2 && a.b_out && a.b1 && a.b2 && a.g1 && a.be1 && a.gsum, "head_mlp: null argument");
   FP_REQUIRE(a.M >= 0 && a.M % 16 == 0, "head_mlp: M=%d must be a multiple of 16", a.M);
   if (a.M == 0) return FP_OK;
   FP_REQUIRE((double)a.M * 1024.0 < 4294967296.0, "head_mlp: M=%d too large for 32-bit lane offsets", a.M);
-  static bool attr_set = false;
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)head_mlp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HM_LDS_BYTES));
-    attr_set = true;
-  }
   ProfScope ps(ctx, s, "linear", 3.0 * 2.0 * (double)a.M * 512.0 * 512.0);
   hipLaunchKernelGGL(head_mlp_kernel, dim3((a.M + 63) / 64), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
   FP_CHECK_HIP(hipGetLastError());

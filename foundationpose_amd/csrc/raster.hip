@@ -697,6 +697,12 @@ RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu) {
   return p;
 }
 
+void raster_kernel_lds(std::vector<KernelLds> &v) {
+  v.push_back({(const void *)classify_faces_kernel, 64 * 1024});
+  v.push_back({(const void *)render_kernel<1>, 148 * 1024});        // the largest strip
+  v.push_back({(const void *)render_kernel<0>, 148 * 1024});
+}
+
 int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
   RenderArgs a = a_in;
   static const int dbg_env = getenv("FP_RENDER_DBG") ? atoi(getenv("FP_RENDER_DBG")) : 0;      // timing experiments only (wrong images): 1 no per-lane rasterisation, 2 no resolve, 4 no triangle pass, 16 no per-wave rasterisation
@@ -716,28 +722,18 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
   unsigned *listA = (unsigned *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes + pl.count_bytes);
   unsigned *listB = (unsigned *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes + pl.count_bytes + pl.list_bytes);
   ProfScope ps(ctx, s, "render", 0);
-  static bool set_c = false;
-  if (!set_c) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)classify_faces_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    set_c = true;
-  }
   hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, recC, recB, recA);
   hipLaunchKernelGGL(classify_faces_kernel, dim3(a.N, pl.G), dim3(RB_THREADS), pl.a_lds, s, a, (const uint2 *)recA, count, listA, listB, pl.S, pl.strip_rows,
                      pl.lds_verts, pl.G, pl.Fg);
   FP_CHECK_HIP(hipGetLastError());
-  auto go = [&](auto kern, bool *attr_set) -> int {
-    if (!*attr_set) {              // once per instantiation, for the largest strip: not a stream operation
-      FP_CHECK_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024));
-      *attr_set = true;
-    }
+  auto go = [&](auto kern) -> int {
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * pl.S)), dim3(RB_THREADS), pl.lds_bytes, s, a, pl.strip_rows, pl.S, (const int4 *)recC,
                        (const float4 *)recB, (const uint2 *)recA, (const int *)count, (const unsigned *)listA, (const unsigned *)listB, pl.lds_verts, pl.G,
                        pl.Fg);
     return FP_OK;
   };
-  static bool set1 = false, set0 = false;
-  if (a.net_out) FP_TRY(go(render_kernel<1>, &set1));
-  else FP_TRY(go(render_kernel<0>, &set0));
+  if (a.net_out) FP_TRY(go(render_kernel<1>));
+  else FP_TRY(go(render_kernel<0>));
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

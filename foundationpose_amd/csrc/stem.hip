@@ -170,12 +170,9 @@ bool stem_supported(const ConvArgs &a) {
          !a.post_add && a.out_ld == 64 && a.split_m >= a.M && a.Ho % ST_BLK == 0 && a.Wo % ST_BLK == 0 && a.H == 2 * a.Ho && a.W == 2 * a.Wo;
 }
 
+void stem_kernel_lds(std::vector<KernelLds> &v) { v.push_back({(const void *)stem7x7_kernel, ST_LDS_BYTES}); }
+
 int launch_stem(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)stem7x7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES));
-    attr_set = true;
-  }
   const int blocks_x = a.Wo / ST_BLK, per_img = blocks_x * (a.Ho / ST_BLK), n_blocks = a.Nimg * per_img, n_pairs = (n_blocks + 1) / 2;
   const int grid = n_pairs < ctx->num_cu ? n_pairs : ctx->num_cu;
   hipLaunchKernelGGL(stem7x7_kernel, dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, (const f16 *)ctx->zero_page, n_pairs, blocks_x, per_img, n_blocks);

@@ -345,15 +345,17 @@ __global__ __launch_bounds__(TG_THREADS, 2) void tok_gemm_kernel(TokGemmArgs p) 
 
 template <int EPI>
 static int tg_launch(const TokGemmArgs &a, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    FP_CHECK_HIP(hipFuncSetAttribute((const void *)tok_gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS_BYTES));
-    attr_set = true;
-  }
   const int n_rt = (a.M + TG_ROWS - 1) / TG_ROWS;
   hipLaunchKernelGGL((tok_gemm_kernel<EPI>), dim3(n_rt * a.nblk), dim3(TG_THREADS), TG_LDS_BYTES, s, a);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
+}
+
+void tok_gemm_kernel_lds(std::vector<KernelLds> &v) {
+  v.push_back({(const void *)tok_gemm_kernel<EPI_ROWS>, TG_LDS_BYTES});
+  v.push_back({(const void *)tok_gemm_kernel<EPI_VT>, TG_LDS_BYTES});
+  v.push_back({(const void *)tok_gemm_kernel<EPI_LN>, TG_LDS_BYTES});
+  v.push_back({(const void *)tok_gemm_kernel<EPI_LNSUM>, TG_LDS_BYTES});
 }
 
 int launch_tok_gemm(fp_ctx *ctx, const TokGemmArgs &a, int epi, hipStream_t s) {

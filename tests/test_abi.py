@@ -49,3 +49,21 @@ def test_missing_library_fails_loudly(monkeypatch, built):
   monkeypatch.setattr(built, 'LIB_PATH', '/nonexistent/libfoundationpose_amd.so')
   with pytest.raises(built.FoundationPoseAmdError):
     built.lib()
+
+
+def test_launch_attributes_are_set_per_device_not_behind_process_wide_flags():
+  """hipFuncAttributeMaxDynamicSharedMemorySize belongs to a function on ONE device: it is set for every kernel of the library in
+  fp_set_kernel_attributes (called by fp_ctx_create on the context's device), never lazily behind a `static bool` in a launcher."""
+  csrc = os.path.join(REPO, 'foundationpose_amd', 'csrc')
+  setters = []
+  for f in sorted(os.listdir(csrc)):
+    if not f.endswith('.hip'):
+      continue
+    txt = open(os.path.join(csrc, f)).read()
+    assert not re.search(r'static\s+bool\s+\w*(attr|set)\w*\s*=', txt), f'{f}: a process-wide flag guards a per-device attribute'
+    setters += [f] * len(re.findall(r'hipFuncSetAttribute\s*\(', txt))
+  assert setters == ['api.hip'], setters
+  api = open(os.path.join(csrc, 'api.hip')).read()
+  body = api[api.index('int fp_set_kernel_attributes'):api.index('extern "C" int fp_ctx_create')]
+  for fn in re.findall(r'void (\w+_kernel_lds)\(', open(os.path.join(csrc, 'common.h')).read()):
+    assert fn + '(v)' in body, f'{fn} is declared in common.h but fp_set_kernel_attributes does not call it'

@@ -422,6 +422,37 @@ def test_band_kernel_equals_halo_kernel(fp, N, C, use_res, relu):
     assert err <= 2e-3 * float(ref.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize('C,HW,sizes', [(512, 20, (8, 32, 50, 70)), (256, 40, (4, 12, 63, 20)), (128, 40, (8, 40, 24, 63))])
+def test_halo_kernel_output_does_not_depend_on_the_tile_size(fp, C, HW, sizes):
+  """The 3x3 stride-1 kernel cuts what is less than a round of 512-pixel tiles into tiles of 1 .. 4 x 128 pixels, whichever finishes first
+  (halo_plan, conv_halo.hip): batches of different sizes therefore run different tile shapes.  A pixel's arithmetic must not depend on
+  the tile it is in: the images two batches share come out BIT-identical, and agree with the fp32 reference.  (Sizes: tiles of 1, 2, 3 and 4
+  x 128 pixels; none of the 1 .. 4-hypothesis launches that run split-K - another accumulation order, its own size class.)"""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  g = torch.Generator(device='cuda').manual_seed(77 + C)
+  nmax = max(sizes)
+  x = torch.randn((nmax, HW, HW, C), device='cuda', generator=g).half().relu()
+  w = (torch.randn((C, C, 3, 3), device='cuda', generator=g) * (2.0 / (C * 9)) ** 0.5).half()
+  b = torch.randn((C,), device='cuda', generator=g) * 0.1
+  res = torch.randn((nmax, HW, HW, C), device='cuda', generator=g).half()
+  wp = _pack_conv_weight(w.float().cpu(), C).cuda()
+  outs = {}
+  for n in sizes:
+    out = torch.full((n, HW, HW, C), float('nan'), dtype=torch.float16, device='cuda')
+    check(lib().fp_conv2d_f16(fp['ctx'].handle, ptr(x), n, HW, HW, C, ptr(wp), ptr(b), C, 3, 3, 1, 1, ptr(res), 1, ptr(out), 0, stream_ptr()))
+    outs[n] = out
+  torch.cuda.synchronize()
+  nmin = min(sizes)
+  for n in sizes:
+    assert not bool(torch.isnan(outs[n]).any())
+    assert torch.equal(outs[n][:nmin], outs[nmin]), f'batch of {n} against batch of {nmin}'
+    m = min(n, sorted(sizes)[1])
+    assert torch.equal(outs[n][:m], outs[sorted(sizes)[1]][:m])
+  ref = torch.relu(torch.nn.functional.conv2d(x[:nmin].float().permute(0, 3, 1, 2), w.float(), b, padding=1) + res[:nmin].float().permute(0, 3, 1, 2))
+  err = float((outs[nmin].float().permute(0, 3, 1, 2) - ref).abs().max())
+  assert err <= 2e-3 * float(ref.abs().max()) + 1e-5
+
+
 def test_conv_rejects_bad_shapes(fp):
   from foundationpose_amd._lib import FoundationPoseAmdError, check, lib, ptr, stream_ptr
   x = torch.zeros((1, 4, 4, 48), dtype=torch.float16, device='cuda')
