@@ -63,7 +63,7 @@ extern int g_halo_tail, g_halo_npw, g_halo_form;
 int fp_set_kernel_attributes(fp_ctx *ctx) {
   std::vector<KernelLds> v;
   conv_kernel_lds(v), conv_halo_kernel_lds(v), conv_s1b_kernel_lds(v), conv_s2_kernel_lds(v), stem_kernel_lds(v);
-  tok_gemm_kernel_lds(v), head_mlp_kernel_lds(v), attn_kernel_lds(v), raster_kernel_lds(v);
+  tok_gemm_kernel_lds(v), tok_qkv_kernel_lds(v), head_mlp_kernel_lds(v), attn_kernel_lds(v), raster_kernel_lds(v);
   FP_CHECK_HIP(hipSetDevice(ctx->device));
   for (const KernelLds &k : v)
     if (k.bytes > 48 * 1024) FP_CHECK_HIP(hipFuncSetAttribute(k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, k.bytes));

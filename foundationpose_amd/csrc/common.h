@@ -206,6 +206,7 @@ void conv_s1b_kernel_lds(std::vector<KernelLds> &v);    // conv_s1b.hip
 void conv_s2_kernel_lds(std::vector<KernelLds> &v);     // conv_s2.hip
 void stem_kernel_lds(std::vector<KernelLds> &v);        // stem.hip
 void tok_gemm_kernel_lds(std::vector<KernelLds> &v);    // tok_gemm.hip
+void tok_qkv_kernel_lds(std::vector<KernelLds> &v);     // tok_qkv.hip
 void head_mlp_kernel_lds(std::vector<KernelLds> &v);    // head_mlp.hip
 void attn_kernel_lds(std::vector<KernelLds> &v);        // attn.hip
 void raster_kernel_lds(std::vector<KernelLds> &v);      // raster.hip
@@ -256,6 +257,7 @@ struct TokGemmBlock {
   void *out;           // fp16 rows (EPI_ROWS / EPI_LN) or the transposed V image (EPI_VT)
   int ld, coff;        // row stride / column offset of this block in `out` (halfs)
   int relu;
+  int vt = 0;          // tok_qkv.hip: 1 = `out` is the transposed V image (tok_gemm.hip takes this from its epilogue argument)
 };
 struct TokGemmArgs {
   const f16 *in;       // [M][512] fp16
@@ -267,6 +269,8 @@ struct TokGemmArgs {
 };
 enum { TG_EPI_ROWS = 0, TG_EPI_VT = 1, TG_EPI_LN = 2, TG_EPI_LNSUM = 3 };
 int launch_tok_gemm(fp_ctx *ctx, const TokGemmArgs &a, int epi, hipStream_t s);
+// tok_qkv.hip: the in-projections - all blocks over a resident 128-token tile (fp16 rows or the transposed V image per block)
+int launch_tok_qkv(fp_ctx *ctx, const TokGemmArgs &a, hipStream_t s);
 // head_mlp.hip: out-projection + LayerNorm1 + linear1 + ReLU + linear2 + LayerNorm2 statistics of one transformer head in one launch
 struct HeadMlpArgs {
   const f16 *att, *tok;        // [M][512]: attention output, residual tokens

@@ -435,17 +435,26 @@ int run_qkv(fp_ctx *ctx, const LinP *const *q, const LinP *const *k, const LinP 
   a.in = tok;
   a.M = N * 400;
   a.tokens = 400;
-  a.nblk = 2 * n_layers;
-  for (int l = 0; l < n_layers; ++l) {
-    a.blk[2 * l] = TokGemmBlock{q[l]->w, q[l]->bias, qk[l], 1024, 0, 0};
-    a.blk[2 * l + 1] = TokGemmBlock{k[l]->w, k[l]->bias, qk[l], 1024, 512, 0};
+  static const bool old_form = getenv("FP_QKV64") != nullptr;          // A/B knob: the 64-token kernel, one launch for q | k, one for v (bit-identical)
+  if (old_form) {
+    a.nblk = 2 * n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+      a.blk[2 * l] = TokGemmBlock{q[l]->w, q[l]->bias, qk[l], 1024, 0, 0};
+      a.blk[2 * l + 1] = TokGemmBlock{k[l]->w, k[l]->bias, qk[l], 1024, 512, 0};
+    }
+    FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_ROWS, s));
+    a.nblk = n_layers;
+    for (int l = 0; l < n_layers; ++l) a.blk[l] = TokGemmBlock{v[l]->w, v[l]->bias, vt[l], 0, 0, 0};
+    return launch_tok_gemm(ctx, a, TG_EPI_VT, s);
   }
-  FP_TRY(launch_tok_gemm(ctx, a, TG_EPI_ROWS, s));
-  a.nblk = n_layers;
+  // ONE launch: every block of every layer over a resident 128-token tile (tok_qkv.hip)
+  a.nblk = 3 * n_layers;
   for (int l = 0; l < n_layers; ++l) {
-    a.blk[l] = TokGemmBlock{v[l]->w, v[l]->bias, vt[l], 0, 0, 0};
+    a.blk[3 * l] = TokGemmBlock{q[l]->w, q[l]->bias, qk[l], 1024, 0, 0, 0};
+    a.blk[3 * l + 1] = TokGemmBlock{k[l]->w, k[l]->bias, qk[l], 1024, 512, 0, 0};
+    a.blk[3 * l + 2] = TokGemmBlock{v[l]->w, v[l]->bias, vt[l], 0, 0, 0, 1};
   }
-  return launch_tok_gemm(ctx, a, TG_EPI_VT, s);
+  return launch_tok_qkv(ctx, a, s);
 }
 
 }  // namespace
@@ -520,7 +529,7 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
 extern "C" int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const float *h_weight, const float *h_bias, int epilogue, int relu,
                                    const void *d_res, const float *h_gamma, const float *h_beta, int tokens, void *d_out, void *stream) {
   FP_REQUIRE(ctx && d_in && h_weight && h_bias && d_out, "fp_token_linear_f16: null argument");
-  FP_REQUIRE(epilogue >= TG_EPI_ROWS && epilogue <= TG_EPI_LNSUM, "fp_token_linear_f16: epilogue %d unknown", epilogue);
+  FP_REQUIRE(epilogue >= TG_EPI_ROWS && epilogue <= TG_EPI_LNSUM + 2, "fp_token_linear_f16: epilogue %d unknown", epilogue);
   FP_CHECK_HIP(hipSetDevice(ctx->device));
   std::vector<f16> hw((size_t)512 * 512);
   pack_tok_weights(h_weight, hw.data());
@@ -544,7 +553,12 @@ extern "C" int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const f
     a.gamma = h_gamma ? d_g : nullptr;
     a.beta = h_beta ? d_b : nullptr;
     a.gsum = (float *)d_out;
-    FP_TRY(launch_tok_gemm(ctx, a, epilogue, (hipStream_t)stream));
+    if (epilogue > TG_EPI_LNSUM) {          // 4 / 5: rows / transposed V image through the 128-token kernel of the in-projections (tok_qkv.hip)
+      a.blk[0].vt = epilogue == TG_EPI_LNSUM + 2;
+      FP_TRY(launch_tok_qkv(ctx, a, (hipStream_t)stream));
+    } else {
+      FP_TRY(launch_tok_gemm(ctx, a, epilogue, (hipStream_t)stream));
+    }
     FP_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
     return FP_OK;
   };

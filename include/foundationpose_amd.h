@@ -218,6 +218,8 @@ int fp_attention_f16(fp_ctx *ctx, const void *d_qk, const void *d_vt, int B, int
  *            1: the same values as the transposed V image [M/tokens][4][128][416] (layout: fp_attention_f16)
  *            2: out = LayerNorm(res + x W^T + b) * gamma + beta, fp16 [M][512] (statistics and residual in fp32)
  *            3: sums over groups of 16 tokens of the normalised rows (before gamma / beta), fp32 [M/16][512]
+ *            4 / 5: epilogues 0 / 1 through the kernel the networks' in-projections run (csrc/tok_qkv.hip: a resident 128-token
+ *               tile, every column block in one launch); bit-identical to 0 / 1
  * h_weight (512x512 row-major) / h_bias / h_gamma / h_beta are host fp32; synchronises the stream. */
 int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const float *h_weight, const float *h_bias, int epilogue, int relu,
                         const void *d_res, const float *h_gamma, const float *h_beta, int tokens, void *d_out, void *stream);

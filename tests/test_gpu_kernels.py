@@ -549,6 +549,33 @@ def test_token_linear_epilogues_vs_fp32_reference(fp, n_hyp):
     assert torch.equal(g1, gs[25:50])
 
 
+@pytest.mark.parametrize('n_hyp', [1, 3, 7, 40])
+def test_token_qkv_equals_the_64_token_kernel(fp, n_hyp):
+  """csrc/tok_qkv.hip - the in-projections of the transformer heads over a resident 128-token tile, all column blocks in one launch -
+  against csrc/tok_gemm.hip's 64-token kernel: fp16 rows (+ReLU) and the transposed V image, BIT-identical (bias first, k ascending in
+  steps of 16, one rounding), and within the fp32 reference's tolerance.  M = 400 n: ragged last tiles; 40 hypotheses = 125 tiles."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  M = 400 * n_hyp
+  g = torch.Generator().manual_seed(500 + n_hyp)
+  x = torch.randn((M, 512), generator=g).half()
+  w = (torch.randn((512, 512), generator=g) * (1.0 / 512) ** 0.5).half().float()
+  b = torch.randn((512,), generator=g) * 0.1
+  x_d = x.cuda()
+
+  def run(epi, relu, out):
+    check(lib().fp_token_linear_f16(fp['ctx'].handle, ptr(x_d), M, ptr(w.numpy()), ptr(b.numpy()), epi, relu, None, None, None, 400, ptr(out), stream_ptr()))
+    return out
+  for relu in (0, 1):
+    a = run(0, relu, torch.full((M, 512), float('nan'), dtype=torch.float16, device='cuda'))
+    c = run(4, relu, torch.full((M, 512), float('nan'), dtype=torch.float16, device='cuda'))
+    assert not bool(torch.isnan(c).any()) and torch.equal(a, c)
+  va = run(1, 0, torch.full((n_hyp, 4, 128, 416), float('nan'), dtype=torch.float16, device='cuda'))
+  vc = run(5, 0, torch.full((n_hyp, 4, 128, 416), float('nan'), dtype=torch.float16, device='cuda'))
+  assert not bool(torch.isnan(vc).any()) and torch.equal(va, vc)
+  lin = x.float() @ w.T + b
+  assert float((c.float().cpu() - torch.relu(lin)).abs().max()) <= 2e-3 * float(lin.abs().max())
+
+
 @pytest.mark.parametrize('T', [400, 384, 230, 64, 37, 1])
 def test_attention_vs_reference(fp, T):
   """Fused MHA core vs softmax(QK^T/sqrt(128))V in fp32 on the same fp16 operands.  P is rounded to
@@ -671,12 +698,12 @@ def test_register_prelude_on_device(sc, fp, golden):
   assert st['n_usable'] == 0 and st['n_mask'] == sc['mask'].sum() and st['median'] == 0
 
 
-@pytest.mark.parametrize('n_hyp', [3, 1, 7])
+@pytest.mark.parametrize('n_hyp', [3, 1, 7, 40])
 def test_head_mlp_vs_fp32_reference(fp, n_hyp):
   """csrc/head_mlp.hip - out-projection + LayerNorm1 + linear1 + ReLU + linear2 + LayerNorm2 sums of one RefineNet head in one launch
   (refine_network.py:56-70,88-91) - against torch fp32 on the same fp16-rounded operands, with x1 and ff rounded to fp16 where the
   kernel rounds them (they are GEMM operands: fp16 in the reference's autocast too).  M = 400 n: 1200 and 2800 tokens end in a ragged
-  64-token tile.  Also: a hypothesis' result does not depend on its place in the batch (bit-exact), and the fused launch agrees with
+  128-token tile, 16 000 are 125 workgroups.  Also: a hypothesis' result does not depend on its place in the batch (bit-exact), and the fused launch agrees with
   the three unfused tok_gemm launches it replaces to fp32 summation order."""
   from foundationpose_amd._lib import check, lib, ptr, stream_ptr
   M = 400 * n_hyp
