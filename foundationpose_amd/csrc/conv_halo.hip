@@ -518,6 +518,12 @@ void halo_plan(int M, int n_ct, int slots, int *n_main, int *nt_tail, int *n_tai
     *n_tail = ((rem + 3) / 4) * n_ct;
     return;
   }
+  static const int force_nt = getenv("FP_HALO_NT") ? atoi(getenv("FP_HALO_NT")) : 0;      // experiments: tiles of this many x 128 pixels for whatever is not a whole round
+  if (force_nt >= 1 && force_nt <= 4) {
+    *nt_tail = force_nt;
+    *n_tail = ((rem + force_nt - 1) / force_nt) * n_ct;
+    return;
+  }
   double best = 1e30;
   for (int nt = 4; nt >= 1; --nt) {
     const int wgs = ((rem + nt - 1) / nt) * n_ct;

@@ -401,7 +401,7 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
   return FP_OK;
 }
 
-// The trunk of a batch as TWO half batches on two streams (from 64 hypotheses on; FP_TRUNK_STREAMS=1: one).  The halves are
+// The trunk of a batch as TWO half batches on two streams (from 48 hypotheses on; FP_TRUNK_STREAMS=1: one).  The halves are
 // independent (nothing in the trunk couples hypotheses) and every 3x3 launch fills the chip alone - one workgroup per CU - so two
 // streams do not run side by side: what they buy is the LAST ROUND of each launch.  At 252 hypotheses a launch is 788 or 1575 tiles on
 // 256 CUs, 3.08 or 6.15 rounds, and the partial last round costs 3 - 8 % of it (as quarter tiles, round 1); with two half-batch launches
@@ -410,7 +410,9 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
 int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0, int NT, int N, f16 **tokens_out, hipStream_t s) {
   static const int n_streams = getenv("FP_TRUNK_STREAMS") ? atoi(getenv("FP_TRUNK_STREAMS")) : 2;
   const size_t img = (size_t)160 * 160 * 8;
-  static const int n_min = getenv("FP_TRUNK_MIN") ? atoi(getenv("FP_TRUNK_MIN")) : 96;       // (64 hypotheses - a tracking frame - run 1 % faster as one batch: 5.60 - 5.65 against 5.70 - 5.77 ms)
+  // from 48 hypotheses on (round 4, refine x5 + score of one object: 40 hypotheses 6.55 ms as one batch / 7.08 split, 48: 7.82 / 7.55, 56: 8.87 / 8.17,
+  // 63: 9.85 / 9.23, 64: 9.95 / 9.32, 96: 13.97 / 13.71; scripts/bench_nhyp.py): below, the halves' tiles get too small
+  static const int n_min = getenv("FP_TRUNK_MIN") ? atoi(getenv("FP_TRUNK_MIN")) : 48;
   if (n_streams < 2 || N < n_min) return run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, tokens_out, s);
   TAKE(tok, f16, (size_t)N * 400 * 512);
   const int n_parts = std::min(n_streams, std::min(fp_ctx::NSIDE, std::max(2, N / 32)));
