@@ -1,5 +1,6 @@
 // extern "C" entry points of libfoundationpose_amd (see include/foundationpose_amd.h).
 #include "common.h"
+#include <memory>
 #include <cstring>
 
 #include <cmath>
@@ -59,6 +60,7 @@ int fp_arena_ensure(fp_ctx *ctx, size_t bytes) {
 }
 
 extern int g_halo_tail, g_halo_npw, g_halo_form;
+static int g_one_chain = 0;      // FP_ONE_CHAIN=1: the two sides of encodeA as one chain (A/B timing; identical results)
 
 int fp_set_kernel_attributes(fp_ctx *ctx) {
   std::vector<KernelLds> v;
@@ -73,6 +75,7 @@ int fp_set_kernel_attributes(fp_ctx *ctx) {
 extern "C" int fp_ctx_create(int device, fp_ctx **out) {
   FP_REQUIRE(out, "fp_ctx_create: null out");
   if (const char *e = getenv("FP_HALO_TAIL")) g_halo_tail = atoi(e) != 0;
+  if (const char *e = getenv("FP_ONE_CHAIN")) g_one_chain = atoi(e) != 0;
   if (const char *e = getenv("FP_HALO_NPW")) g_halo_npw = atoi(e) == 2 ? 2 : 4;
   if (const char *e = getenv("FP_HALO_FORM")) g_halo_form = atoi(e);
   int n = 0;
@@ -571,10 +574,15 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
     float *tr = d_trans ? d_trans : trans, *ro = d_rot ? d_rot : rot;
     const int n_runs = count_runs(objs, n_obj);
     TAKE(rscratch, char, rs_total);                              // reused by every iteration
+    // One run of like objects in a batch that the trunk does not cut in two by hypotheses: the rendered side (crop window -> rasteriser ->
+    // encodeA) and the observed side (crop window -> observed crop -> encodeA) are two chains on two streams up to the channel concat
+    // (run_trunk): side B does not wait for the rasteriser.  Bit-identical to one chain.
+    const bool two_sides = n_runs == 1 && N < fp_trunk_split_min() && !g_one_chain;
     for (int it = 0; it < iteration; ++it) {
       size_t voff = 0;
       int off = 0, k = 0;
-      StreamFanout fo(ctx, s, n_runs);
+      StreamFanout fo(ctx, s, two_sides ? 1 : n_runs);
+      std::unique_ptr<StreamFanout> ab;
       for (int o = 0; o < n_obj;) {       // per run of like objects: crop windows + render (side A); per object: observed crop (side B)
         int e = o + 1, cnt = objs[o].n;
         while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
@@ -583,22 +591,29 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
           hipStream_t so = fo.stream_for(k++);
           float *p = d_poses + (size_t)off * 16;
           FP_TRY(launch_crop_window_tf(p, cnt, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
+          if (two_sides) ab.reset(new StreamFanout(ctx, s, 2));          // forks behind the crop windows
           const size_t rsb = (render_plan(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu).total + 255) & ~(size_t)255;
-          FP_TRY(render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
-                                 cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, rscratch + voff, rsb, so));
+          int rc = render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
+                                   cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, rscratch + voff, rsb, so);
           voff += rsb;
-          for (int q = o; q < e; ++q) {
+          hipStream_t sb = ab ? ab->stream_for(0) : so;
+          for (int q = o; q < e && rc == FP_OK; ++q) {
             const fp_object_batch &oq = objs[q];
             if (oq.n == 0) continue;
-            FP_TRY(fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, oq.n, 160, 160, 0,
-                                    oq.mesh_diameter, cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, so));
+            rc = fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, oq.n, 160, 160, 0,
+                                  oq.mesh_diameter, cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, sb);
             off += oq.n;
+          }
+          if (rc != FP_OK) {
+            if (ab) (void)ab->join();
+            (void)fo.join();
+            return rc;
           }
         }
         o = e;
       }
       FP_TRY(fo.join());
-      FP_TRY(fp_refine_forward(ctx, net, net_in, N, tr, ro, s));     // ONE network pass for every object
+      FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get()));     // ONE network pass for every object (joins `ab`)
       // pose update: one launch per run of objects with the same translation scale (one launch when they share a mesh)
       off = 0;
       for (int o = 0; o < n_obj;) {
@@ -648,7 +663,10 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
     int off = 0, k = 0;
     TAKE(rscratch, char, rs_total);
     size_t voff = 0;
-    StreamFanout fo(ctx, s, count_runs(objs, n_obj));
+    const int n_runs = count_runs(objs, n_obj);
+    const bool two_sides = n_runs == 1 && N < fp_trunk_split_min() && !g_one_chain;       // as in fp_refine_predict_multi
+    StreamFanout fo(ctx, s, two_sides ? 1 : n_runs);
+    std::unique_ptr<StreamFanout> ab;
     for (int o = 0; o < n_obj;) {
       int e = o + 1, cnt = objs[o].n;
       while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
@@ -657,22 +675,29 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
         hipStream_t so = fo.stream_for(k++);
         const float *p = d_poses + (size_t)off * 16;
         FP_TRY(launch_crop_window_tf(p, cnt, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
+        if (two_sides) ab.reset(new StreamFanout(ctx, s, 2));
         const size_t rsb = (render_plan(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu).total + 255) & ~(size_t)255;
-        FP_TRY(render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
-                               net_in + (size_t)off * img, rscratch + voff, rsb, so));
+        int rc = render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
+                                 net_in + (size_t)off * img, rscratch + voff, rsb, so);
         voff += rsb;
-        for (int q = o; q < e; ++q) {
+        hipStream_t sb = ab ? ab->stream_for(0) : so;
+        for (int q = o; q < e && rc == FP_OK; ++q) {
           const fp_object_batch &oq = objs[q];
           if (oq.n == 0) continue;
-          FP_TRY(fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, oq.n, 160, 160, 1,
-                                  oq.mesh_diameter, normalize_xyz, 1, net_in + ((size_t)N + off) * img, so));
+          rc = fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, oq.n, 160, 160, 1,
+                                oq.mesh_diameter, normalize_xyz, 1, net_in + ((size_t)N + off) * img, sb);
           off += oq.n;
+        }
+        if (rc != FP_OK) {
+          if (ab) (void)ab->join();
+          (void)fo.join();
+          return rc;
         }
       }
       o = e;
     }
     FP_TRY(fo.join());
-    FP_TRY(fp_score_features(ctx, net, net_in, N, d_feats, s));
+    FP_TRY(fp_score_features_ab(ctx, net, net_in, N, d_feats, s, ab.get()));
     return FP_OK;
   };
   int rc = body();

@@ -147,6 +147,13 @@ struct StreamFanout {
 };
 
 
+// net.hip: the network passes with the two sides of encodeA as two chains (`ab` forked by the caller: side B's input is produced on
+// ab->stream_for(0), side A's on `s`; nullptr: one chain); batches below fp_trunk_split_min() hypotheses only (larger ones are cut in two by hypotheses)
+struct fp_net;
+int fp_trunk_split_min();
+int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab);
+int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, hipStream_t s, StreamFanout *ab);
+
 // profiling hooks (events on the launch stream)
 struct ProfScope {
   fp_ctx *ctx;

@@ -49,6 +49,14 @@ static int fp_hyp_chunk(int n_total) {
   return ch;
 }
 
+int fp_trunk_split_min() {
+  // from 48 hypotheses on (round 4, refine x5 + score of one object: 40 hypotheses 6.55 ms as one batch / 7.08 split, 48: 7.82 / 7.55, 56: 8.87 / 8.17,
+  // 63: 9.85 / 9.23, 64: 9.95 / 9.32, 96: 13.97 / 13.71; scripts/bench_nhyp.py): below, the halves' tiles get too small
+  static const int n_min = getenv("FP_TRUNK_MIN") ? atoi(getenv("FP_TRUNK_MIN")) : 48;
+  static const int n_streams = getenv("FP_TRUNK_STREAMS") ? atoi(getenv("FP_TRUNK_STREAMS")) : 2;
+  return n_streams < 2 ? 0x7fffffff : n_min;
+}
+
 namespace {
 
 struct SD {
@@ -348,8 +356,14 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
     return FP_ENOMEM;                                                                     \
   }
 
-// shared trunk -> tokens (N*400, 512) fp16, positional embedding added
-int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int N, f16 **tokens_out, hipStream_t s, f16 *tok_dst = nullptr) {
+// shared trunk -> tokens (N*400, 512) fp16, positional embedding added.
+// `ab` (optional): the two sides of encodeA as two chains on two streams.  encodeA runs on cat([A, B], 0) with shared weights
+// (refine_network.py:74-78): nothing couples the rendered side A and the observed side B before the channel concat, and in a fused
+// pass side A waits for the rasteriser while side B (observed crop -> stem -> ...) does not.  The caller has forked `ab` (two chains),
+// side B's input is produced on ab->stream_for(0), side A's on `s`; the chains join in front of encodeAB.  Each side's launches are the
+// 2N-image launches cut in two: a pixel's arithmetic does not depend on its batch, so the tokens are those of the single chain bit for bit.
+int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int N, f16 **tokens_out, hipStream_t s, f16 *tok_dst = nullptr,
+              StreamFanout *ab = nullptr) {
   const ConvW *t = net->trunk;
   const size_t n2 = (size_t)2 * N;
   TAKE(a0, f16, n2 * 80 * 80 * 64);
@@ -374,6 +388,24 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
     sk = sk_;
   }
   Conv2dCall c;
+  if (ab && ab->fan) {
+    // encodeA / encoderA, one chain per side; side `h` owns images [h N, h N + N) of every buffer (and its own half of the split-K scratch)
+    for (int h = 0; h < 2; ++h) {
+      hipStream_t st = h == 0 ? s : ab->stream_for(0);
+      float *skh = sk ? sk + (size_t)h * 4 * N * 1600 * 128 : nullptr;
+      const size_t o80 = (size_t)h * N * 80 * 80 * 64, o40 = (size_t)h * N * 1600 * 128;
+      c = Conv2dCall{h == 0 ? xA : xB, N, 160, 160, &t[0]}; c.out = a0 + o80; FP_TRY(run_conv(ctx, c, st, skh));
+      c = Conv2dCall{a0 + o80, N, 80, 80, &t[1]}; c.out = a1 + o40; FP_TRY(run_conv(ctx, c, st, skh));
+      c = Conv2dCall{a1 + o40, N, 40, 40, &t[2]}; c.out = tA + o40; FP_TRY(run_conv(ctx, c, st, skh));
+      c = Conv2dCall{tA + o40, N, 40, 40, &t[3]}; c.res = a1 + o40; c.out = a2 + o40; FP_TRY(run_conv(ctx, c, st, skh));
+      c = Conv2dCall{a2 + o40, N, 40, 40, &t[4]}; c.out = tA + o40; FP_TRY(run_conv(ctx, c, st, skh));
+      // the channel concat cat((a,b),1): side A -> channels [0,128), side B -> [128,256) of the same rows
+      c = Conv2dCall{tA + o40, N, 40, 40, &t[5]}; c.res = a2 + o40; c.out = ab0; c.out_ld = 256;
+      if (h == 1) c.split_m = 0, c.coff_hi = 128;
+      FP_TRY(run_conv(ctx, c, st, skh));
+    }
+    FP_TRY(ab->join());
+  } else {
   // encodeA / encoderA on cat([A,B],0)
   // (A and B halves of the net tensor may come from different places when the batch is processed in chunks)
   c = Conv2dCall{xA, N, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s, sk));
@@ -385,6 +417,7 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
   // last conv of encodeA writes the channel-concat cat((a,b),1) directly: image n<N -> channels [0,128), n>=N -> [128,256)
   c = Conv2dCall{tA, (int)n2, 40, 40, &t[5]}; c.res = a2; c.out = ab0; c.out_ld = 256; c.split_m = N * 1600; c.coff_hi = 128;
   FP_TRY(run_conv(ctx, c, s, sk));
+  }
   // encodeAB
   c = Conv2dCall{ab0, N, 40, 40, &t[6]}; c.out = tB; FP_TRY(run_conv(ctx, c, s, sk));
   c = Conv2dCall{tB, N, 40, 40, &t[7]}; c.res = ab0; c.out = ab1; FP_TRY(run_conv(ctx, c, s, sk));
@@ -407,23 +440,24 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
 // 256 CUs, 3.08 or 6.15 rounds, and the partial last round costs 3 - 8 % of it (as quarter tiles, round 1); with two half-batch launches
 // queued on two streams the workgroups of the other half start on the CUs the last round leaves idle.  Results are those of the single
 // batch bit for bit (a hypothesis' arithmetic does not depend on its batch).
-int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0, int NT, int N, f16 **tokens_out, hipStream_t s) {
+int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0, int NT, int N, f16 **tokens_out, hipStream_t s, StreamFanout *ab = nullptr) {
   static const int n_streams = getenv("FP_TRUNK_STREAMS") ? atoi(getenv("FP_TRUNK_STREAMS")) : 2;
   const size_t img = (size_t)160 * 160 * 8;
-  // from 48 hypotheses on (round 4, refine x5 + score of one object: 40 hypotheses 6.55 ms as one batch / 7.08 split, 48: 7.82 / 7.55, 56: 8.87 / 8.17,
-  // 63: 9.85 / 9.23, 64: 9.95 / 9.32, 96: 13.97 / 13.71; scripts/bench_nhyp.py): below, the halves' tiles get too small
-  static const int n_min = getenv("FP_TRUNK_MIN") ? atoi(getenv("FP_TRUNK_MIN")) : 48;
-  if (n_streams < 2 || N < n_min) return run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, tokens_out, s);
+  if (N < fp_trunk_split_min()) return run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, tokens_out, s, nullptr, ab);
+  if (ab) FP_TRY(ab->join());          // (a batch that is cut in two by hypotheses keeps both sides of a half on one stream)
   TAKE(tok, f16, (size_t)N * 400 * 512);
   const int n_parts = std::min(n_streams, std::min(fp_ctx::NSIDE, std::max(2, N / 32)));
   StreamFanout fo(ctx, s, n_parts);
   f16 *t = nullptr;
-  for (int k = 0, a0 = 0; k < n_parts; ++k) {
+  int rc = FP_OK;
+  for (int k = 0, a0 = 0; k < n_parts && rc == FP_OK; ++k) {
     const int a1 = (int)((long long)N * (k + 1) / n_parts);
-    FP_TRY(run_trunk(ctx, net, in + (s0 + a0) * img, in + ((size_t)NT + s0 + a0) * img, a1 - a0, &t, k == 0 ? s : fo.stream_for(k - 1), tok + (size_t)a0 * 400 * 512));
+    rc = run_trunk(ctx, net, in + (s0 + a0) * img, in + ((size_t)NT + s0 + a0) * img, a1 - a0, &t, k == 0 ? s : fo.stream_for(k - 1), tok + (size_t)a0 * 400 * 512);
     a0 = a1;
   }
-  FP_TRY(fo.join());
+  const int rj = fo.join();            // on every path: the caller resets the arena, which the side streams may still be writing
+  FP_TRY(rc);
+  FP_TRY(rj);
   *tokens_out = tok;
   return FP_OK;
 }
@@ -463,11 +497,15 @@ int run_qkv(fp_ctx *ctx, const LinP *const *q, const LinP *const *k, const LinP 
 
 extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot,
                                  void *stream) {
+  return fp_refine_forward_ab(ctx, net, d_net_in, N, d_trans, d_rot, (hipStream_t)stream, nullptr);
+}
+
+// `ab`: side B of the network input is being produced on ab->stream_for(0), side A on `s` (the fused passes of api.hip): run_trunk
+int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab) {
   FP_REQUIRE(ctx && net && d_net_in && d_trans && d_rot, "fp_refine_forward: null argument");
   FP_REQUIRE(net->kind == FP_NET_REFINE, "fp_refine_forward: not a RefineNet");
   FP_REQUIRE(N >= 0, "fp_refine_forward: N<0");
-  if (N == 0) return FP_OK;
-  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) return ab ? ab->join() : FP_OK;
   const int NT = N;                                   // whole batch
   const int CH = fp_hyp_chunk(NT);
   FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(CH)));
@@ -475,7 +513,7 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
   auto body = [&](int s0, int N) -> int {
     f16 *tok = nullptr;
     const f16 *in = (const f16 *)d_net_in;
-    FP_TRY(run_trunk_maybe_split(ctx, net, in, s0, NT, N, &tok, s));
+    FP_TRY(run_trunk_maybe_split(ctx, net, in, s0, NT, N, &tok, s, CH == NT ? ab : nullptr));
     const int M = N * 400;
     // The translation and rotation heads are independent transformer layers on the same tokens: each gets its own
     // buffers and its own stream, so the tail of one head's kernels overlaps the other's (their launches are 3.08 rounds of
@@ -520,10 +558,12 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
   // hypothesis chunks (FP_CHUNK, default: the whole batch in one pass) reuse the SAME arena addresses.  Chunking to keep
   // producer -> consumer tensors inside the 256 MiB Infinity Cache was measured and is slower (smaller grids, same traffic)
   int rc = FP_OK;
+  if (ab && CH != NT) rc = ab->join();          // (hypothesis chunks: one chain)
   for (int s0 = 0; s0 < NT && rc == FP_OK; s0 += CH) {
     rc = body(s0, std::min(CH, NT - s0));
     ctx->arena.off = mark;
   }
+  if (ab && rc != FP_OK) (void)ab->join();      // never leave the side stream unjoined
   return rc;
 }
 
@@ -624,11 +664,14 @@ extern "C" int fp_net_tokens(fp_ctx *ctx, const fp_net *net, const void *d_net_i
 }
 
 extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, void *stream) {
+  return fp_score_features_ab(ctx, net, d_net_in, N, d_feats, (hipStream_t)stream, nullptr);
+}
+
+int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, hipStream_t s, StreamFanout *ab) {
   FP_REQUIRE(ctx && net && d_net_in && d_feats, "fp_score_features: null argument");
   FP_REQUIRE(net->kind == FP_NET_SCORE, "fp_score_features: not a ScoreNetMultiPair");
   FP_REQUIRE(N >= 0, "fp_score_features: N<0");
-  if (N == 0) return FP_OK;
-  hipStream_t s = (hipStream_t)stream;
+  if (N == 0) return ab ? ab->join() : FP_OK;
   const int NT = N;
   const int CH = fp_hyp_chunk(NT);
   FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(CH)));
@@ -636,7 +679,7 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
   auto body = [&](int s0, int N) -> int {
     f16 *tok = nullptr;
     const f16 *in = (const f16 *)d_net_in;
-    FP_TRY(run_trunk_maybe_split(ctx, net, in, s0, NT, N, &tok, s));
+    FP_TRY(run_trunk_maybe_split(ctx, net, in, s0, NT, N, &tok, s, CH == NT ? ab : nullptr));
     const int M = N * 400;
     TAKE(qk, f16, (size_t)M * 1024);
     TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
@@ -653,10 +696,12 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
     return FP_OK;
   };
   int rc = FP_OK;
+  if (ab && CH != NT) rc = ab->join();
   for (int s0 = 0; s0 < NT && rc == FP_OK; s0 += CH) {
     rc = body(s0, std::min(CH, NT - s0));
     ctx->arena.off = mark;
   }
+  if (ab && rc != FP_OK) (void)ab->join();
   return rc;
 }
 
