@@ -169,7 +169,7 @@ def tracking_fps(est, device, n_frames):
   out = {'frames': n_frames, 'sequence': 'seeded smooth SE(3) trajectory, <= 1 cm and <= 2 deg per frame, 480x640 RGB-D frames resident in HBM'}
   start = poses[0].clone()
   for name, fn, n in (('track_one', lambda f: est.track_one(rgbs[f], depths[f], K, iteration=2), n_frames),
-                      ('track_multi_64', lambda f: est.track_multi(rgbs[f], depths[f], K, iteration=2, n_hypotheses=64), max(n_frames // 4, 50))):
+                      ('track_multi_64', lambda f: est.track_multi(rgbs[f], depths[f], K, iteration=2, n_hypotheses=64), n_frames)):
     for graph in (False, True):
       est.enable_track_graph(graph)
       est.pose_last = start.clone()
@@ -183,6 +183,23 @@ def tracking_fps(est, device, n_frames):
       dt = time.perf_counter() - t0
       out[name + ('_graph' if graph else '')] = {'fps': n / dt, 'ms_per_frame': dt / n * 1e3, 'frames_timed': n}
   est.enable_track_graph(False)
+  return out
+
+
+def shard_local_ms(est, objects, device, steps=5):
+  """Local time of the largest shard of an N-way job (configs[2]: ONE object, rank 0's ceil(252 / N) hypotheses through refinement and
+  feature extraction; no all-gather, no tail), measured on this GPU: what bounds the strong-scaling step of a 2 / 4 / 8-GPU job."""
+  out = {}
+  for world in (2, 4, 8):
+    one = lambda: step_local(est, objects[:1], world, 0)
+    for _ in range(2):
+      one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      one()
+    torch.cuda.synchronize()
+    out[str(math.ceil(N_HYP / world))] = (time.perf_counter() - t0) / steps * 1e3
   return out
 
 
@@ -203,8 +220,8 @@ def pmc_traffic():
 def cpu_baseline():
   """The CPU oracle timed on this host's cores on a bounded sample of the same workload.  Protocol: one warm-up pass on 8
   hypotheses (thread pools, the C rasteriser's first call), then ONE timed pass on 126 hypotheses (half of configs[1]) with
-  est_refine_iter=5 + scoring - 10-15 s on 16 threads; not SURVEY 8(d)'s median-of-5 on configs[0], which measures a
-  different (32-hypothesis, 1-iteration) workload."""
+  est_refine_iter=5 + scoring - 10-15 s on 16 threads - the workload of `value`; then SURVEY 8(d)'s own protocol as `configs0`: BASELINE
+  configs[0] (32 hypotheses, est_refine_iter=1 + score), one warm-up, median of 5 (~1.2 s each)."""
   from tests import util
   from oracle.predict import OracleFoundationPose
   from foundationpose_amd import synthetic as S
@@ -223,9 +240,22 @@ def cpu_baseline():
   t0 = time.time()
   orc.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=ITER, chunk=16)
   dt = time.time() - t0
+  # SURVEY.md 8(d)'s protocol beside it: configs[0] (32 hypotheses, est_refine_iter=1 + score), one warm-up, median of 5
+  o32 = mk(32)
+  o32.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=1, chunk=16)
+  t32 = []
+  for _ in range(5):
+    t1 = time.time()
+    o32.register(sc['K'], sc['rgb'], sc['depth'], sc['mask'], iteration=1, chunk=16)
+    t32.append(time.time() - t1)
+  med = sorted(t32)[2]
   return dict(value=n_s / dt, unit='pose-hypotheses/sec', cores=cores, kind='port',
               sample=f'{n_s} hypotheses of the same scene (half of configs[1]), est_refine_iter={ITER} + score, one timed pass after a warm-up '
-                     f'pass: oracle/ (torch-CPU fp32 nets + C/OpenMP rasteriser), {dt:.1f} s wall incl. depth filtering')
+                     f'pass: oracle/ (torch-CPU fp32 nets + C/OpenMP rasteriser), {dt:.1f} s wall incl. depth filtering',
+              configs0=dict(value=32 / med, unit='pose-hypotheses/sec', cores=cores, seconds_per_register=med,
+                            hypothesis_passes_per_sec=32 * 2 / med,
+                            sample='BASELINE configs[0] / SURVEY.md 8(d): 32 hypotheses, est_refine_iter=1 + score (2 network passes per hypothesis), '
+                                   'one warm-up, median of 5 register() calls incl. depth filtering'))
 
 
 def launch_ranks(args, argv):
@@ -391,6 +421,9 @@ def main(argv=None):
     extras['configs3_4x252'] = {'objects': 4, 'value': 4 * N_HYP * args.steps / dt3, 'unit': 'pose-hypotheses/sec',
                                 'ms_per_step': dt3 / args.steps * 1e3}
     if world == 1:
+      extras['shard_local_ms'] = shard_local_ms(est, objects, device)
+      extras['shard_local_ms_note'] = ('local ms per step of the largest shard of a 2 / 4 / 8-GPU configs[2] job (126 / 63 / 32 hypotheses of the one object: '
+                                       'refine x5 + score features), measured on this one GPU; the all-gather and the replicated tail come on top')
       extras['tracking_configs4'] = tracking_fps(est, device, n_frames=1000)
 
   if rank == 0:
@@ -429,9 +462,12 @@ def main(argv=None):
       'phases_ms_per_rank': [dict(zip(('local', 'allgather', 'tail'), [float(x) for x in p.tolist()])) for p in ph_all],
     }
     out['kernel_classes'] = classes       # HIP-event time per kernel class, from an untimed pass of the same K steps
-    out['kernel_classes_note'] = ('linear / attention: RefineNet runs its two transformer heads on two streams, their launches overlap '
-                                  'and each counts its own span (sum > wall time); heads_wall = first in-projection .. join of the heads on the main stream '
-                                  '(their wall-clock share, one span per network pass); the convolution classes and render run alone')
+    out['kernel_classes_note'] = ('ms_per_step = sum of the launch spans, busy_ms_per_step = time with at least one launch of the class executing. The classes '
+                                  'OVERLAP: the trunk runs as two half batches on two streams (two launches of a convolution class in flight: spans sum to about '
+                                  'twice the busy time) and RefineNet runs its two transformer heads on two streams (linear / attention likewise); kernels of '
+                                  'different classes overlap too (the tail of one half batch beside the other half, a head beside the other head): the busy times '
+                                  'of all classes sum to 1 - 2 % more than the step. heads_wall = first in-projection .. join of the heads on the main stream '
+                                  '(their wall-clock share, one span per network pass)')
     out.update(extras)
     if not args.no_cpu_baseline and world == 1:        # timed on rank 0 of the single-GPU run only
       out['cpu_baseline'] = cpu_baseline()

@@ -90,7 +90,10 @@ def nvdiffrast_render(K=None, H=None, W=None, ob_in_cams=None, glctx=None, conte
   xyz = torch.empty((N, h, w, 3), dtype=torch.float, device=dev)
   normal = torch.empty((N, h, w, 3), dtype=torch.float, device=dev) if get_normal else None
   default_light = light_color is None and light_dir is not None and np.array_equal(np.asarray(light_dir, dtype=float).reshape(-1), [0, 0, 1])
-  if projection_mat is None and (default_light or not use_light):
+  # extra={'rast': ...} asks for dr.rasterize's own output as well (u, v, z/w, triangle id + 1 per pixel: src/Utils.py:182's rast_out, rows
+  # flipped like the images) - the reference keeps it internal; the parity tests compare coverage and the winning face on it
+  rast = torch.empty((N, h, w, 4), dtype=torch.float, device=dev) if 'rast' in extra else None
+  if projection_mat is None and (default_light or not use_light) and rast is None:
     Kd, Kp = k_ptr(K)
     check(lib().fp_render(ctx.handle, dm.handle, ptr(poses), N, Kp, int(H), int(W), ptr(bb), h, w, 1 if use_light else 0,
                           float(w_ambient), float(w_diffuse), ptr(color), ptr(depth), ptr(normal), ptr(xyz), stream_ptr(dev)))
@@ -118,9 +121,12 @@ def nvdiffrast_render(K=None, H=None, W=None, ob_in_cams=None, glctx=None, conte
     Kp = None
     if K is not None:
       Kd, Kp = k_ptr(K)
+    o.d_rast = ptr(rast)
     check(lib().fp_render_ex(ctx.handle, dm.handle, ptr(poses), N, Kp, int(H), int(W), ptr(bb), h, w, ctypes.byref(o), ptr(color), ptr(depth),
                              ptr(normal), ptr(xyz), stream_ptr(dev)))
   extra['xyz_map'] = xyz
+  if rast is not None:
+    extra['rast'] = rast
   return color, depth, normal
 
 

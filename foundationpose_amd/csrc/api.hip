@@ -298,33 +298,13 @@ extern "C" int fp_crop_window_tf(fp_ctx *ctx, const float *d_poses, int N, const
 // A render called on its own (the nvdiffrast_render API, fp_render_net): its scratch (transformed vertices + strip face lists) comes
 // from the context's arena and is released when the launches are queued - the next taker runs behind them on the same stream.
 static int render_with_arena_scratch(fp_ctx *ctx, RenderArgs &a, hipStream_t s) {
-  if (a.N <= 0) return launch_render(ctx, a, s);
-  // The face lists are sized for the worst case (every face in every strip): a large batch at a large output size (many strips) is
-  // rendered in sub-batches so that the scratch stays below 1 GiB (a sub-batch's launches run behind the previous one's: one scratch).
-  const int N = a.N;
-  int chunk = N;
-  static const size_t cap = getenv("FP_RENDER_SCRATCH_MAX") ? (size_t)atoll(getenv("FP_RENDER_SCRATCH_MAX")) : ((size_t)1 << 30);      // (tests lower it)
-  while (chunk > 1 && render_plan(chunk, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu).total > cap) chunk = (chunk + 1) / 2;
-  const RenderPlan pl = render_plan(chunk, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
-  FP_TRY(fp_arena_ensure(ctx, pl.total + 4096));
+  if (a.N == 0) return FP_OK;
+  const size_t bytes = render_scratch_bytes(a.N, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);     // (sub-batches above 1 GiB: launch_render)
+  FP_TRY(fp_arena_ensure(ctx, bytes + 4096));
   const size_t mark = ctx->arena.off;
-  void *scratch = ctx->arena.take(pl.total);
-  int rc = scratch ? FP_OK : FP_ENOMEM;
-  const size_t px = (size_t)a.Ho * a.Wo;
-  for (int b0 = 0; b0 < N && rc == FP_OK; b0 += chunk) {
-    RenderArgs c = a;
-    c.N = std::min(chunk, N - b0);
-    c.poses = a.poses + (size_t)b0 * 16;
-    if (a.bbox2d) c.bbox2d = a.bbox2d + (size_t)b0 * 4;
-    if (a.color) c.color = a.color + b0 * px * 3;
-    if (a.depth) c.depth = a.depth + b0 * px;
-    if (a.normal) c.normal = a.normal + b0 * px * 3;
-    if (a.xyz) c.xyz = a.xyz + b0 * px * 3;
-    if (a.net_out) c.net_out = a.net_out + b0 * px * 8;
-    c.scratch = scratch;
-    c.scratch_bytes = pl.total;       // (a smaller last sub-batch needs no more than a full one)
-    rc = launch_render(ctx, c, s);
-  }
+  a.scratch = ctx->arena.take(bytes);
+  a.scratch_bytes = bytes;
+  const int rc = a.scratch ? launch_render(ctx, a, s) : FP_ENOMEM;
   ctx->arena.off = mark;
   return rc;
 }
@@ -384,6 +364,7 @@ extern "C" int fp_render_ex(fp_ctx *ctx, const fp_mesh *mesh, const float *d_pos
   a.depth = d_depth;
   a.normal = d_normal;
   a.xyz = d_xyz;
+  a.rast = opts->d_rast;
   return render_with_arena_scratch(ctx, a, (hipStream_t)stream);
 }
 
@@ -522,14 +503,14 @@ static bool same_render_key(const fp_object_batch &a, const fp_object_batch &b) 
   return a.mesh == b.mesh && a.H == b.H && a.W == b.W && a.mesh_diameter == b.mesh_diameter && memcmp(a.K, b.K, 9 * sizeof(double)) == 0;
 }
 
-// Scratch of the renders of a pass: one render_plan(...).total per run of like objects (the renders of the runs may overlap on side
-// streams, so each has its own block).
+// Scratch of the renders of a pass: one render_scratch_bytes(...) per run of like objects (the renders of the runs may overlap on side
+// streams, so each has its own block; a run whose worst case exceeds 1 GiB is rendered in sub-batches: launch_render).
 static size_t render_scratch_total(fp_ctx *ctx, const fp_object_batch *objs, int n_obj) {
   size_t bytes = 0;
   for (int o = 0; o < n_obj;) {
     int e = o + 1, cnt = objs[o].n;
     while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
-    if (cnt > 0) bytes += (render_plan(cnt, objs[o].mesh->d.V, objs[o].mesh->d.F, 160, 160, ctx->num_cu).total + 255) & ~(size_t)255;
+    if (cnt > 0) bytes += (render_scratch_bytes(cnt, objs[o].mesh->d.V, objs[o].mesh->d.F, 160, 160, ctx->num_cu) + 255) & ~(size_t)255;
     o = e;
   }
   return bytes;
@@ -592,7 +573,7 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
           float *p = d_poses + (size_t)off * 16;
           FP_TRY(launch_crop_window_tf(p, cnt, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
           if (two_sides) ab.reset(new StreamFanout(ctx, s, 2));          // forks behind the crop windows
-          const size_t rsb = (render_plan(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu).total + 255) & ~(size_t)255;
+          const size_t rsb = (render_scratch_bytes(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu) + 255) & ~(size_t)255;
           int rc = render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
                                    cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, rscratch + voff, rsb, so);
           voff += rsb;
@@ -676,7 +657,7 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
         const float *p = d_poses + (size_t)off * 16;
         FP_TRY(launch_crop_window_tf(p, cnt, ob.K, crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
         if (two_sides) ab.reset(new StreamFanout(ctx, s, 2));
-        const size_t rsb = (render_plan(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu).total + 255) & ~(size_t)255;
+        const size_t rsb = (render_scratch_bytes(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu) + 255) & ~(size_t)255;
         int rc = render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter, normalize_xyz, 0.1f,
                                  net_in + (size_t)off * img, rscratch + voff, rsb, so);
         voff += rsb;

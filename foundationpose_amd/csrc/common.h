@@ -307,6 +307,7 @@ struct RenderArgs {
   int use_light;
   float w_ambient, w_diffuse;
   float *color, *depth, *normal, *xyz;  // mode 0
+  float *rast = nullptr;                // mode 0, optional: dr.rasterize's output per pixel (u, v, z/w, triangle id + 1) - src/Utils.py:182; parity tests
   f16 *net_out;                         // mode 1
   float mesh_diameter, invalid_thres;
   int normalize_xyz;
@@ -327,7 +328,12 @@ struct RenderPlan {
   size_t lds_bytes, a_lds, c_bytes, b_bytes, a_bytes, count_bytes, list_bytes, total;
 };
 RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu);
-int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s);
+// A render of N hypotheses goes out in sub-batches of render_chunk(...) when the worst-case scratch of all N at once (two face lists of
+// every face in every strip: N * S * F * 8 B) would exceed 1 GiB (FP_RENDER_SCRATCH_MAX; tests lower it): the sub-batches run behind
+// each other on the stream, over ONE scratch of render_scratch_bytes(...), with one plan (strips, face ranges) for all of them.
+int render_chunk(int N, int V, int F, int Ho, int Wo, int num_cu);
+size_t render_scratch_bytes(int N, int V, int F, int Ho, int Wo, int num_cu);
+int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s);      // a.scratch: render_scratch_bytes(a.N, ...) bytes
 int launch_crop_window_tf(const float *poses, int N, const double *K, double crop_ratio, double diameter, int ow, int oh, float *tf,
                           float *bbox, hipStream_t s);
 

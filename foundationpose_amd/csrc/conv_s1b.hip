@@ -199,7 +199,8 @@ __global__ __launch_bounds__(B1_THREADS, 2) void conv3x3_s1_band_kernel(ConvArgs
 
 bool s1b_supported(const ConvArgs &a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.out_mode == 0 && !a.post_add && a.H == B1_W && a.W == B1_W && a.Cin % 32 == 0 &&
-         a.Cout % 128 == 0 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0 && a.wpk != nullptr && !(a.splitk && a.ksplit > 1);
+         a.Cout % 128 == 0 && a.Kpad == 9 * a.Cin && a.out_ld % 8 == 0 && a.coff_hi % 8 == 0 && a.wpk != nullptr && !(a.splitk && a.ksplit > 1) &&
+         (long long)a.Nimg * B1_W * B1_W * a.Cin * 2 < (1ll << 31);        // 32-bit byte offsets into the input (above: the general 3x3 kernel, 4 GB)
 }
 
 void conv_s1b_kernel_lds(std::vector<KernelLds> &v) {

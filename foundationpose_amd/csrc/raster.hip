@@ -172,17 +172,12 @@ __device__ void clip_matrix(const RenderArgs &a, int b, const float *pose, float
 //   B (2 x float4): camera-space position (pts_cam, src/Utils.py:168) and the vertex' Lambert term (src/Utils.py:200-206) - the
 //               expressions the per-pixel resolve evaluated until round 3, moved here verbatim -, then colour and w.
 #define RB_A_NONE 0x7fff7fffu
-__global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 *__restrict__ recC, float4 *__restrict__ recB, uint2 *__restrict__ recA) {
-  __shared__ float sM[16];
-  __shared__ float sP[12];
-  const int b = blockIdx.y;
-  if (threadIdx.x == 0) {
-    clip_matrix(a, b, a.poses + (size_t)b * 16, sM);
-    for (int i = 0; i < 12; ++i) sP[i] = a.poses[(size_t)b * 16 + i];
-  }
-  __syncthreads();
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= a.mesh.V) return;
+struct VtxRecords {
+  int4 c;
+  uint2 a;
+  float4 b0, b1;
+};
+__device__ __forceinline__ VtxRecords vertex_records(const RenderArgs &a, int v, const float *sM, const float *sP) {
   float M[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) M[i] = sM[i];
@@ -213,16 +208,35 @@ __global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 
     const float dt = fmaf(nc[0] / nn, L[0] / ln, fmaf(nc[1] / nn, L[1] / ln, (nc[2] / nn) * (L[2] / ln)));
     dv = fminf(fmaxf(dt, 0.f), 1.f);
   }
-  const size_t r = (size_t)b * m.V + v;
-  recC[r] = make_int4(o.ok ? o.X : (int)0x80000000, o.Y, __float_as_int(o.zn), __float_as_int(o.w));
+  VtxRecords r;
+  r.c = make_int4(o.ok ? o.X : (int)0x80000000, o.Y, __float_as_int(o.zn), __float_as_int(o.w));
   const bool small = o.ok && abs(o.X) < 16384 && abs(o.Y) < 16384;
   // (where A cannot describe the vertex its second word carries w instead of z/w: the classification drops faces whose three
   // vertices are all on or behind the camera plane - a drifted tracking pose puts the whole mesh there - without reading C)
-  recA[r] = small ? make_uint2(((unsigned)o.X & 0xffffu) | ((unsigned)o.Y << 16), __float_as_uint(o.zn)) : make_uint2(RB_A_NONE, __float_as_uint(o.w));
-  recB[2 * r] = make_float4(pc[0], pc[1], pc[2], dv);
-  float4 cw = make_float4(0.f, 0.f, 0.f, o.w);
-  if (m.vcolor) cw.x = m.vcolor[v * 3], cw.y = m.vcolor[v * 3 + 1], cw.z = m.vcolor[v * 3 + 2];
-  recB[2 * r + 1] = cw;
+  r.a = small ? make_uint2(((unsigned)o.X & 0xffffu) | ((unsigned)o.Y << 16), __float_as_uint(o.zn)) : make_uint2(RB_A_NONE, __float_as_uint(o.w));
+  r.b0 = make_float4(pc[0], pc[1], pc[2], dv);
+  r.b1 = make_float4(0.f, 0.f, 0.f, o.w);
+  if (m.vcolor) r.b1.x = m.vcolor[v * 3], r.b1.y = m.vcolor[v * 3 + 1], r.b1.z = m.vcolor[v * 3 + 2];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 *__restrict__ recC, float4 *__restrict__ recB, uint2 *__restrict__ recA) {
+  __shared__ float sM[16];
+  __shared__ float sP[12];
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) {
+    clip_matrix(a, b, a.poses + (size_t)b * 16, sM);
+    for (int i = 0; i < 12; ++i) sP[i] = a.poses[(size_t)b * 16 + i];
+  }
+  __syncthreads();
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= a.mesh.V) return;
+  const VtxRecords q = vertex_records(a, v, sM, sP);
+  const size_t r = (size_t)b * a.mesh.V + v;
+  recC[r] = q.c;
+  recA[r] = q.a;
+  recB[2 * r] = q.b0;
+  recB[2 * r + 1] = q.b1;
 }
 
 #define RB_SMALL 4                      // candidate pixels of a "small" triangle
@@ -236,20 +250,44 @@ __global__ __launch_bounds__(256) void xform_vertices_kernel(RenderArgs a, int4 
 // a handful of hypotheses - tracking - would otherwise leave the classification to a handful of workgroups).  Per (hypothesis b, strip s,
 // range g): count[((b*S + s)*G + g)*4 + {0,1,2}] = small, medium, list-B entries; listA[(b*S + s)*G*Fg + g*Fg ..]: small from the
 // front of the range's segment, medium from its back; listB likewise: large 32-bit triangles and RB_SLOW ones.
-__global__ __launch_bounds__(RB_THREADS) void classify_faces_kernel(RenderArgs a, const uint2 *__restrict__ recA, int *__restrict__ count,
-                                                                   unsigned *__restrict__ listA, unsigned *__restrict__ listB, int S, int strip_rows,
-                                                                   int lds_verts, int G, int Fg) {
+// FUSED (the A records fit LDS: lds_verts): the vertex pre-pass runs HERE - every workgroup of a hypothesis transforms all its vertices
+// (it needs their A records in LDS for its face range anyway; 8 vertices per thread) and writes the records of its own share to global
+// memory for the strip kernel: one launch and one LDS fill from global memory less than xform_vertices_kernel + this kernel.
+template <bool FUSED>
+__global__ __launch_bounds__(RB_THREADS) void classify_faces_kernel(RenderArgs a, uint2 *__restrict__ recA, int4 *__restrict__ recC, float4 *__restrict__ recB,
+                                                                   int *__restrict__ count, unsigned *__restrict__ listA, unsigned *__restrict__ listB, int S,
+                                                                   int strip_rows, int lds_verts, int G, int Fg) {
   extern __shared__ __attribute__((aligned(16))) uint2 cl_ldsA[];
   __shared__ int cs[RB_MAXS + 1][3];
+  __shared__ float sM[16];
+  __shared__ float sP[12];
   const int b = blockIdx.x, grp = blockIdx.y;
   const MeshDev &m = a.mesh;
   const uint2 *gA = recA + (size_t)b * m.V;
   const int f0 = grp * Fg, f1 = min(m.F, f0 + Fg);
   for (int i = threadIdx.x; i < S * 3; i += RB_THREADS) cs[i / 3][i % 3] = 0;
-  if (lds_verts)
+  if constexpr (FUSED) {
+    if (threadIdx.x == 0) {
+      clip_matrix(a, b, a.poses + (size_t)b * 16, sM);
+      for (int i = 0; i < 12; ++i) sP[i] = a.poses[(size_t)b * 16 + i];
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < m.V; v += RB_THREADS) {
+      const VtxRecords q = vertex_records(a, v, sM, sP);
+      cl_ldsA[v] = q.a;
+      if ((v / RB_THREADS) % G == grp) {               // this workgroup's share of the hypothesis' records
+        const size_t r = (size_t)b * m.V + v;
+        recC[r] = q.c;
+        recA[r] = q.a;
+        recB[2 * r] = q.b0;
+        recB[2 * r + 1] = q.b1;
+      }
+    }
+  } else if (lds_verts) {
     for (int i = threadIdx.x; i < m.V; i += RB_THREADS) cl_ldsA[i] = gA[i];
+  }
   __syncthreads();
-  auto getA = [&](int i) -> uint2 { return lds_verts ? cl_ldsA[i] : gA[i]; };
+  auto getA = [&](int i) -> uint2 { return (FUSED || lds_verts) ? cl_ldsA[i] : gA[i]; };
   const size_t seg = (size_t)G * Fg;                     // list entries per (hypothesis, strip)
   unsigned *lA = listA + (size_t)b * S * seg + (size_t)grp * Fg, *lB = listB + (size_t)b * S * seg + (size_t)grp * Fg;
   int4 f_n = make_int4(0, 0, 0, 0);
@@ -288,6 +326,7 @@ __global__ __launch_bounds__(RB_THREADS) void classify_faces_kernel(RenderArgs a
   for (int i = threadIdx.x; i < S * 3; i += RB_THREADS) count[(((size_t)b * S + i / 3) * G + grp) * 4 + i % 3] = cs[i / 3][i % 3];
 }
 
+// MODE 0: the API form (fp32 channels-last maps), 1: the fused network tensor, 2: dr.rasterize's own output only (u, v, z/w, triangle id + 1: parity tests)
 template <int MODE>
 __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int strip_rows, int n_strips, const int4 *__restrict__ recC,
                                                             const float4 *__restrict__ recB, const uint2 *__restrict__ recA, const int *__restrict__ count,
@@ -481,14 +520,15 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   // the three A records (LDS) and the three 32-byte B records - 7 scattered 16-byte loads on 4 cache lines (27 + 9 scattered 4-byte
   // loads until round 3, with the position / normal transform and Lambert term of all three vertices recomputed per pixel).
   float P0 = 0.f, P1 = 0.f, P2 = 0.f, P4 = 0.f, P5 = 0.f, P6 = 0.f, P8 = 0.f, P9 = 0.f, P10 = 0.f;
-  if (MODE == 0) {                      // the API form also interpolates the camera-space normals
+  constexpr bool API = MODE == 0, RAST = MODE == 2;
+  if (API) {                            // the API form also interpolates the camera-space normals
     P0 = pose[0], P1 = pose[1], P2 = pose[2], P4 = pose[4], P5 = pose[5], P6 = pose[6], P8 = pose[8], P9 = pose[9], P10 = pose[10];
   }
-  auto emit = [&](int p, const float *col, const float *nrm, const float *p3) __attribute__((always_inline)) {
+  auto emit = [&](int p, const float *col, const float *nrm, const float *p3, const float *r4) __attribute__((always_inline)) {
     const int jl = p / Wo, i = p - jl * Wo;
     const int jo = Ho - 1 - (row0 + jl);  // flipped output row (src/Utils.py:216-218)
     const size_t o = ((size_t)b * Ho + jo) * Wo + i;
-    if (MODE == 0) {
+    if (API) {
       if (a.color) {
         a.color[o * 3] = col[0];
         a.color[o * 3 + 1] = col[1];
@@ -505,6 +545,8 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
         a.xyz[o * 3 + 2] = p3[2];
       }
       if (a.depth) a.depth[o] = p3[2];
+    } else if (RAST) {
+      *reinterpret_cast<float4 *>(a.rast + o * 4) = make_float4(r4[0], r4[1], r4[2], r4[3]);
     } else {
       // rgbAs = (color*255)/255 (predict_pose_refine.py:57 + h5_dataset.py:123); xyz transform h5_dataset.py:92-99 | 151-156
       float r[6];
@@ -541,8 +583,8 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
       if (covered) covq[base + __builtin_popcountll(mk & ((1ull << lane) - 1))] = (unsigned short)p;
     }
     if (p < npix && !covered) {
-      const float z3[3] = {0.f, 0.f, 0.f};
-      emit(p, z3, z3, z3);
+      const float z3[4] = {0.f, 0.f, 0.f, 0.f};
+      emit(p, z3, z3, z3, z3);
     }
   }
   __syncthreads();
@@ -552,7 +594,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     const int jl = p / Wo, i = p - jl * Wo;
     const int j = row0 + jl;
     const unsigned long long key = zbuf[p];
-    float col[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, p3[3] = {0, 0, 0};
+    float col[3] = {0, 0, 0}, nrm[3] = {0, 0, 0}, p3[3] = {0, 0, 0}, r4[4] = {0, 0, 0, 0};
     {
       int t = (int)(unsigned)(key & 0xffffffffull);
       const int4 f4 = m.faces4[t];
@@ -577,6 +619,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
         float q0 = b0 / rc0.w, q1 = b1 / rc1.w, q2 = b2 / rc2.w;
         float qs = (q0 + q1) + q2;
         u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
+        if (RAST) r4[2] = fmaf(b2, __uint_as_float(a2.y), fmaf(b1, __uint_as_float(a1.y), b0 * __uint_as_float(a0.y)));
       } else {
         const Vtx v0 = unpack(vc[i0]), v1 = unpack(vc[i1]), v2 = unpack(vc[i2]);
         if (!(v0.ok && v1.ok && v2.ok)) {         // straddles the camera plane: weights from the homogeneous edge functions
@@ -589,6 +632,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
           (void)clip_eval(T, i, j, l, &zp);
           const float ls = __fadd_rn(__fadd_rn(l[0], l[1]), l[2]);
           u = __fdiv_rn(l[0], ls), v = __fdiv_rn(l[1], ls), w2 = (1.f - u) - v;
+          if (RAST) r4[2] = zp;
         } else {
           long long X0 = v0.X, Y0 = v0.Y, X1 = v1.X, Y1 = v1.Y, X2 = v2.X, Y2 = v2.Y;
           long long area = (X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0);
@@ -603,13 +647,16 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
           float q0 = b0 / v0.w, q1 = b1 / v1.w, q2 = b2 / v2.w;
           float qs = (q0 + q1) + q2;
           u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
+          if (RAST) r4[2] = fmaf(b2, v2.zn, fmaf(b1, v1.zn, b0 * v0.zn));
         }
       }
+      if (RAST) r4[0] = u, r4[1] = v, r4[3] = (float)(t + 1);
+      if (!RAST) {
       // camera-space position and Lambert term of the three vertices: the pre-pass' records
       const float pc[3][3] = {{rb0.x, rb0.y, rb0.z}, {rb1.x, rb1.y, rb1.z}, {rb2.x, rb2.y, rb2.z}};
       const float dv[3] = {rb0.w, rb1.w, rb2.w};
       float nc[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-      if (MODE == 0) {
+      if (API) {
         const int idx[3] = {i0, i1, i2};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -662,8 +709,9 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
       nn = nn > 1e-12f ? nn : 1e-12f;
 #pragma unroll
       for (int c = 0; c < 3; ++c) nrm[c] = nrm[c] / nn;
+      }
     }
-    emit(p, col, nrm, p3);
+    emit(p, col, nrm, p3, r4);
   }
 }
 
@@ -698,12 +746,27 @@ RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu) {
 }
 
 void raster_kernel_lds(std::vector<KernelLds> &v) {
-  v.push_back({(const void *)classify_faces_kernel, 64 * 1024});
+  v.push_back({(const void *)classify_faces_kernel<true>, 64 * 1024});
+  v.push_back({(const void *)classify_faces_kernel<false>, 64 * 1024});
   v.push_back({(const void *)render_kernel<1>, 148 * 1024});        // the largest strip
   v.push_back({(const void *)render_kernel<0>, 148 * 1024});
+  v.push_back({(const void *)render_kernel<2>, 148 * 1024});
 }
 
-int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
+int render_chunk(int N, int V, int F, int Ho, int Wo, int num_cu) {
+  static const size_t cap = getenv("FP_RENDER_SCRATCH_MAX") ? (size_t)atoll(getenv("FP_RENDER_SCRATCH_MAX")) : ((size_t)1 << 30);
+  int chunk = N < 1 ? 1 : N;
+  while (chunk > 1 && render_plan(chunk, V, F, Ho, Wo, num_cu).total > cap) chunk = (chunk + 1) / 2;
+  return chunk;
+}
+
+size_t render_scratch_bytes(int N, int V, int F, int Ho, int Wo, int num_cu) {
+  return render_plan(render_chunk(N, V, F, Ho, Wo, num_cu), V, F, Ho, Wo, num_cu).total;
+}
+
+// one sub-batch; plan_n: the batch size the plan (strips, face ranges, list strides) is made for (>= a.N: a smaller last sub-batch runs on
+// the plan of the full ones, so the scratch of a full one always holds it)
+static int launch_render_one(fp_ctx *ctx, const RenderArgs &a_in, int plan_n, hipStream_t s) {
   RenderArgs a = a_in;
   static const int dbg_env = getenv("FP_RENDER_DBG") ? atoi(getenv("FP_RENDER_DBG")) : 0;      // timing experiments only (wrong images): 1 no per-lane rasterisation, 2 no resolve, 4 no triangle pass, 16 no per-wave rasterisation
   a.dbg = dbg_env;
@@ -711,7 +774,7 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
   if (a.N == 0) return FP_OK;
   FP_REQUIRE((size_t)a.Wo * 10 <= 64 * 1024, "render: output width %d too large for one LDS strip", a.Wo);
   FP_REQUIRE(a.mesh.F < (1 << 30), "render: %d faces", a.mesh.F);
-  const RenderPlan pl = render_plan(a.N, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
+  const RenderPlan pl = render_plan(plan_n, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
   FP_REQUIRE(pl.S <= RB_MAXS && pl.strip_rows * a.Wo <= 65535, "render: output %dx%d needs %d strips of %d pixels", a.Ho, a.Wo, pl.S, pl.strip_rows * a.Wo);
   FP_REQUIRE(a.scratch && a.scratch_bytes >= pl.total, "render: scratch of %zu bytes needed, %zu given", pl.total, a.scratch_bytes);
   char *sc = (char *)a.scratch;
@@ -722,9 +785,17 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
   unsigned *listA = (unsigned *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes + pl.count_bytes);
   unsigned *listB = (unsigned *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes + pl.count_bytes + pl.list_bytes);
   ProfScope ps(ctx, s, "render", 0);
-  hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, recC, recB, recA);
-  hipLaunchKernelGGL(classify_faces_kernel, dim3(a.N, pl.G), dim3(RB_THREADS), pl.a_lds, s, a, (const uint2 *)recA, count, listA, listB, pl.S, pl.strip_rows,
-                     pl.lds_verts, pl.G, pl.Fg);
+  static const bool two_launches = getenv("FP_RENDER_PREPASS2") != nullptr;       // A/B knob: vertex pre-pass and classification as two launches (identical images)
+  // fused where one workgroup per hypothesis classifies (G == 1: from 64 hypotheses on): 220 -> 210 us at 252 hypotheses, 144 -> 136 at 126; with
+  // the faces of a hypothesis cut into G ranges every range's workgroup would redo the vertex pass (32 hypotheses: 70 -> 73 us, 1: 32 -> 34)
+  if (pl.lds_verts && pl.G == 1 && !two_launches) {
+    hipLaunchKernelGGL(classify_faces_kernel<true>, dim3(a.N, pl.G), dim3(RB_THREADS), pl.a_lds, s, a, recA, recC, recB, count, listA, listB, pl.S,
+                       pl.strip_rows, pl.lds_verts, pl.G, pl.Fg);
+  } else {
+    hipLaunchKernelGGL(xform_vertices_kernel, dim3((a.mesh.V + 255) / 256, a.N), dim3(256), 0, s, a, recC, recB, recA);
+    hipLaunchKernelGGL(classify_faces_kernel<false>, dim3(a.N, pl.G), dim3(RB_THREADS), pl.a_lds, s, a, recA, recC, recB, count, listA, listB, pl.S,
+                       pl.strip_rows, pl.lds_verts, pl.G, pl.Fg);
+  }
   FP_CHECK_HIP(hipGetLastError());
   auto go = [&](auto kern) -> int {
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * pl.S)), dim3(RB_THREADS), pl.lds_bytes, s, a, pl.strip_rows, pl.S, (const int4 *)recC,
@@ -732,9 +803,34 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a_in, hipStream_t s) {
                        pl.Fg);
     return FP_OK;
   };
-  if (a.net_out) FP_TRY(go(render_kernel<1>));
-  else FP_TRY(go(render_kernel<0>));
+  if (a.net_out) {
+    FP_TRY(go(render_kernel<1>));
+  } else {
+    if (a.color || a.depth || a.normal || a.xyz) FP_TRY(go(render_kernel<0>));
+    if (a.rast) FP_TRY(go(render_kernel<2>));        // (a second pass over the same lists: the parity tests' output)
+  }
   FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s) {
+  FP_REQUIRE(a.N >= 0 && a.Ho > 0 && a.Wo > 0, "render: bad shape N=%d out=%dx%d", a.N, a.Ho, a.Wo);
+  if (a.N == 0) return FP_OK;
+  const int chunk = render_chunk(a.N, a.mesh.V, a.mesh.F, a.Ho, a.Wo, ctx->num_cu);
+  const size_t px = (size_t)a.Ho * a.Wo;
+  for (int b0 = 0; b0 < a.N; b0 += chunk) {
+    RenderArgs c = a;
+    c.N = a.N - b0 < chunk ? a.N - b0 : chunk;
+    c.poses = a.poses + (size_t)b0 * 16;
+    if (a.bbox2d) c.bbox2d = a.bbox2d + (size_t)b0 * 4;
+    if (a.color) c.color = a.color + b0 * px * 3;
+    if (a.depth) c.depth = a.depth + b0 * px;
+    if (a.normal) c.normal = a.normal + b0 * px * 3;
+    if (a.xyz) c.xyz = a.xyz + b0 * px * 3;
+    if (a.rast) c.rast = a.rast + b0 * px * 4;
+    if (a.net_out) c.net_out = a.net_out + b0 * px * 8;
+    FP_TRY(launch_render_one(ctx, c, chunk, s));
+  }
   return FP_OK;
 }
 

@@ -32,8 +32,11 @@ def depth_to_vis(depth, zmin=None, zmax=None, mode='rgb', inverse=True):
     else:
       inside = (d > lo) & (d < hi)
       level = np.where(inside, (d - lo) / (hi - lo), 1.0)
-  gray = np.clip(np.nan_to_num(level) * 255, 0, 255).astype(np.uint8)
-  return gray if mode == 'gray' else _jet(gray)
+    # src/Utils.py:473-476: 'gray' clips to [0, 255] before the uint8 cast, 'rgb' casts (vis * 255) WITHOUT a clip - with a caller-supplied
+    # zmin above the nearest depth the inverse levels exceed 1 and wrap in the cast, as they do in the reference
+    if mode == 'gray':
+      return (level * 255).clip(0, 255).astype(np.uint8)
+    return _jet((level * 255).astype(np.uint8))
 
 
 def make_grid_image(imgs, nrow, padding=5, pad_value=255):

@@ -77,6 +77,8 @@ typedef struct fp_render_opts {
   float light_color[3];
   int has_projection;      /* 1: projection (row-major 4x4, the reference's projection_mat) replaces the matrix derived from K */
   double projection[16];
+  float *d_rast;           /* optional device output N*h*w*4: dr.rasterize's (u, v, z/w, triangle_id + 1) per pixel (src/Utils.py:182), rows flipped like
+                            * the other outputs; NULL: not written.  What the parity tests compare coverage and the winning face on. */
 } fp_render_opts;
 int fp_render_ex(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
                  const float *d_bbox2d, int out_h, int out_w, const fp_render_opts *opts,

@@ -138,8 +138,10 @@ def pose_update(cfg, poseA, trans, rot, mesh_diameter, tf_to_crops=None, Ks=None
 
 
 @torch.no_grad()
-def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_tensors, mesh_diameter, iteration=5, chunk=16, trace=None):
-  """PoseRefinePredictor.predict (predict_pose_refine.py:150-237), fp32 (no autocast on CPU)."""
+def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_tensors, mesh_diameter, iteration=5, chunk=16, trace=None, autocast=False):
+  """PoseRefinePredictor.predict (predict_pose_refine.py:150-237), fp32; autocast=True: the network under
+  torch.autocast('cpu', dtype=torch.float16) - the reference's own precision on the GPU (predict_pose_refine.py:190) - with the
+  outputs taken back to fp32 for the pose update, as the reference does (`output[k].float()`, :195-200)."""
   B_in_cams = torch.as_tensor(ob_in_cams, dtype=torch.float32)
   rgb_t = torch.as_tensor(rgb, dtype=torch.float32)
   depth_t = torch.as_tensor(depth, dtype=torch.float32)
@@ -150,7 +152,12 @@ def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_tensors, me
     for b in range(0, len(B_in_cams), chunk):
       A = torch.cat([pd['rgbAs'][b:b + chunk], pd['xyz_mapAs'][b:b + chunk]], dim=1).float()
       Bt = torch.cat([pd['rgbBs'][b:b + chunk], pd['xyz_mapBs'][b:b + chunk]], dim=1).float()
-      o = nets.refine_forward(sd, A, Bt, cfg['use_BN'])
+      if autocast:
+        with torch.autocast('cpu', dtype=torch.float16):
+          o = nets.refine_forward(sd, A, Bt, cfg['use_BN'])
+        o = {k: v.float() for k, v in o.items()}
+      else:
+        o = nets.refine_forward(sd, A, Bt, cfg['use_BN'])
       new_pose, td, rd = pose_update(cfg, pd['poseA'][b:b + chunk], o['trans'], o['rot'], mesh_diameter,
                                      tf_to_crops=pd['tf_to_crops'][b:b + chunk], Ks=np.asarray(K, dtype=np.float32))
       outs.append((new_pose, o['trans'], o['rot']))

@@ -36,20 +36,34 @@ def test_crop_window_tf(sc, fp):
 def _render_pair(sc, fp, poses, bbox, out, mt_cpu=None, use_light=True):
   from oracle.render import nvdiffrast_render as orender
   mt_cpu = mt_cpu or sc['mt']
-  eo, eg = {}, {}
+  eo, eg = {}, {'rast': None}
   co, do, no = orender(K=sc['K'], H=480, W=640, ob_in_cams=poses, mesh_tensors=mt_cpu, bbox2d=bbox, output_size=out,
                        use_light=use_light, get_normal=True, extra=eo)
   cg, dg, ng = fp['U'].nvdiffrast_render(K=sc['K'], H=480, W=640, ob_in_cams=torch.from_numpy(poses).cuda(),
                                          mesh_tensors=util.to_dev(mt_cpu), bbox2d=None if bbox is None else bbox.cuda(),
                                          output_size=out, use_light=use_light, get_normal=True, extra=eg)
+  _assert_same_coverage_and_faces(eo['rast'], eg['rast'].cpu())
   return (co, do, no, eo['xyz_map']), (cg.cpu(), dg.cpu(), ng.cpu(), eg['xyz_map'].cpu())
+
+
+def _assert_same_coverage_and_faces(rast_o, rast_g, what=''):
+  """dr.rasterize's output (u, v, z/w, triangle id + 1) of the oracle and of the HIP rasteriser: WHICH pixels are covered and WHICH face
+  wins each of them is index work - 64-bit integer edge functions on vertices snapped to 1/16 px, nearest z/w, ties to the lower face
+  id - on both sides from the same float32 vertex transform: compared exactly.  Only the interpolated floats carry an allowance."""
+  id_o, id_g = rast_o[..., 3].numpy().astype(np.int64), rast_g[..., 3].numpy().astype(np.int64)
+  n_cov = int(((id_o > 0) != (id_g > 0)).sum())
+  n_face = int((id_o != id_g).sum())
+  print(f'rasteriser {what}: {int((id_o > 0).sum())} covered pixels, coverage differs on {n_cov}, winning face on {n_face}')
+  assert n_cov == 0 and n_face == 0, f'{what}: coverage differs on {n_cov} pixels, the winning face on {n_face}'
+  d = (rast_o[..., :3] - rast_g[..., :3]).abs()
+  assert float(d.max()) <= 2e-6, f'{what}: barycentrics / z/w differ by {float(d.max()):.2e}'
 
 
 @pytest.mark.parametrize('textured', [False, True])
 def test_render_crops_match_oracle(sc, fp, textured):
-  """Rasteriser: coverage is decided in integer arithmetic -> identical pixel sets; interpolants are the
-  same fmaf chains -> agree to float32 rounding (1e-6 abs on values <= 1).  Allowance: 1e-4 of the
-  pixels may differ (a 1-ulp difference in a snapped vertex flips an edge pixel)."""
+  """Rasteriser: coverage and the winning face are decided in integer arithmetic -> IDENTICAL pixel sets and face ids (asserted
+  exactly, _assert_same_coverage_and_faces); interpolants are the same fmaf chains -> agree to float32 rounding (2e-6 abs on
+  values <= 1; the allowance is for these floats only)."""
   from oracle import geometry as G
   s = util.scene(0, textured=textured) if textured else sc
   poses = util.hypotheses(s, 12, jitter_seed=5)
@@ -57,7 +71,7 @@ def test_render_crops_match_oracle(sc, fp, textured):
   bbox = G.crop_bbox2d_ori(tf, (160, 160))
   ref, got = _render_pair(s, fp, poses, bbox, (160, 160), mt_cpu=s['mt'])
   cov_o, cov_g = ref[1] > 0, got[1] > 0
-  assert float((cov_o != cov_g).float().mean()) <= 1e-4
+  assert torch.equal(cov_o, cov_g)                   # (coverage and the winning face: compared exactly inside _render_pair)
   assert float(cov_o.float().mean()) > 0.15          # the object fills a good part of the crop
   for name, a, b in zip(('color', 'depth', 'normal', 'xyz'), ref, got):
     frac, mx, med = util.mismatch_report(a.numpy(), b.numpy(), 2e-6)
@@ -86,13 +100,14 @@ def test_render_light_and_projection_arguments(sc, fp, variant):
     K2 = s['K'].copy()
     K2[0, 1] = 3.0
     kw.update(projection_mat=projection_matrix_from_intrinsics(K2, height=480, width=640, znear=0.05, zfar=20.0))
-  eo, eg = {}, {}
+  eo, eg = {}, {'rast': None}
   co, do, no = orender(K=s['K'], H=480, W=640, ob_in_cams=poses, mesh_tensors=s['mt'], bbox2d=bbox, output_size=(160, 160), get_normal=True,
                        extra=eo, **kw)
   cg, dg, ng = fp['U'].nvdiffrast_render(K=s['K'], H=480, W=640, ob_in_cams=torch.from_numpy(poses).cuda(), mesh_tensors=util.to_dev(s['mt']),
                                          bbox2d=bbox.cuda(), output_size=(160, 160), get_normal=True, extra=eg, **kw)
   assert float((do > 0).float().mean()) > 0.15
-  assert float(((do > 0) != (dg.cpu() > 0)).float().mean()) <= 1e-4
+  _assert_same_coverage_and_faces(eo['rast'], eg['rast'].cpu(), variant)
+  assert torch.equal(do > 0, dg.cpu() > 0)
   for name, a, b in (('color', co, cg), ('depth', do, dg), ('normal', no, ng), ('xyz', eo['xyz_map'], eg['xyz_map'])):
     frac, mx, _ = util.mismatch_report(a.numpy(), b.cpu().numpy(), 2e-6)
     assert frac <= 2e-4, f'{variant} {name}: {frac:.2e} of values differ by > 2e-6 (max {mx:.2e})'
@@ -792,18 +807,21 @@ def test_render_mesh_too_large_for_lds_and_wide_output(fp):
       assert frac <= 2e-4, f'{out} {name}: {frac:.2e} of values differ by > 2e-6 (max {mx:.2e})'
 
 
-def test_render_in_sub_batches(tmp_path):
-  """A standalone render whose worst-case scratch (face lists sized for every face in every strip) exceeds the limit is rendered in
-  sub-batches (api.hip: render_with_arena_scratch; 1 GiB by default - 220 full-frame poses).  With the limit lowered to 4 MB in a child
-  process (the knob is read once per process) 12 crops go out in sub-batches of one or two: bit-identical to the single launch."""
+@pytest.mark.parametrize('n_crops,limit', [(12, 4000000), (65, 34000000)])
+def test_render_in_sub_batches(tmp_path, n_crops, limit):
+  """A render whose worst-case scratch (face lists sized for every face in every strip) exceeds the limit goes out in sub-batches
+  (raster.hip: launch_render; 1 GiB by default - 220 full-frame poses) - the standalone render of the nvdiffrast_render API and the render
+  inside a fused refinement pass alike.  With the limit lowered in a child process (the knob is read once per process): 12 crops in
+  sub-batches of one or two; 65 crops as 33 + 32, where a plan made for the last 32 alone would use other strips than the one the
+  scratch was sized for (every sub-batch runs on the plan of a full one).  Images and refined poses bit-identical to the single launch."""
   import os, subprocess, sys
   script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'render_dump.py')
   outs = []
-  for name, env in (('whole', {}), ('chunked', {'FP_RENDER_SCRATCH_MAX': '4000000'})):
+  for name, env in (('whole', {}), ('chunked', {'FP_RENDER_SCRATCH_MAX': str(limit)})):
     path = str(tmp_path / (name + '.npz'))
-    r = subprocess.run([sys.executable, script, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, script, path], env=dict(os.environ, N_CROPS=str(n_crops), **env), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
     outs.append(np.load(path))
-  for k in ('c', 'd', 'n', 'x'):
+  for k in ('c', 'd', 'n', 'x', 'r'):
     assert np.array_equal(outs[0][k], outs[1][k]), k
   assert float((outs[0]['d'] > 0).mean()) > 0.15

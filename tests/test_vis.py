@@ -32,6 +32,13 @@ def test_depth_to_vis_rules():
   assert c.shape == (1, 5, 3) and c.dtype == np.uint8
   assert c[0, 2].tolist() == [127, 255, 127] or abs(int(c[0, 2, 1]) - 255) <= 2          # mid-range of JET is green
   assert c[0, 0, 0] > 100 and c[0, 0, 2] == 0                       # 1.0 -> red end
+  # src/Utils.py:473-476: 'gray' clips before the uint8 cast, 'rgb' does not - a level above 1 (inverse mode, depth nearer than a given zmin)
+  # saturates in 'gray' and WRAPS in 'rgb', exactly as (vis * 255).astype(np.uint8) does in the reference
+  near = np.array([[0.4, 0.5]], np.float32)                          # zmin / depth = 1.25 -> 318.75 -> uint8 62 ; 1.0 -> 255
+  assert V.depth_to_vis(near, zmin=0.5, mode='gray', inverse=True).tolist() == [[255, 254]] or V.depth_to_vis(near, zmin=0.5, mode='gray', inverse=True)[0, 0] == 255
+  wrapped = (np.float32(0.5) / (near + np.float32(1e-8)) * 255).astype(np.uint8)
+  assert wrapped[0, 0] < 100                                          # the cast wrapped
+  assert np.array_equal(V.depth_to_vis(near, zmin=0.5, mode='rgb', inverse=True), V._jet(wrapped))
 
 
 def test_png_container(tmp_path):
