@@ -605,7 +605,10 @@ int launch_head_mlp(fp_ctx *ctx, const HeadMlpArgs &a, hipStream_t s) {
   FP_REQUIRE((double)a.M * 1024.0 < 4294967296.0, "head_mlp: M=%d too large for 32-bit lane offsets", a.M);
   ProfScope ps(ctx, s, "linear", 3.0 * 2.0 * (double)a.M * 512.0 * 512.0);
   static const bool form64 = getenv("FP_HEADMLP64") != nullptr;       // A/B knob: the 64-token form (two resident tiles)
-  if (form64) hipLaunchKernelGGL(head_mlp_kernel, dim3((a.M + 63) / 64), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
+  // 1 .. 4 hypotheses (tracking): the 64-token form.  Every workgroup streams all 1.5 MB of weights whatever its tile holds, so a launch
+  // of a handful of workgroups lasts one workgroup's life: 26.8 us for seven 64-token tiles against 38.5 for four 128-token ones at one
+  // hypothesis.  (Its own size class, like split-K in the 3x3 kernel: the two forms differ in the last bits, see the 128-token form's header.)
+  if (form64 || a.M <= 1600) hipLaunchKernelGGL(head_mlp_kernel, dim3((a.M + 63) / 64), dim3(HM_THREADS), HM_LDS_BYTES, s, a);
   else hipLaunchKernelGGL(head_mlp128_kernel, dim3((a.M + H2_ROWS - 1) / H2_ROWS), dim3(HM_THREADS), H2_LDS_BYTES, s, a);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
