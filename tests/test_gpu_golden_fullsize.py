@@ -178,24 +178,32 @@ def test_full_gain_chain_on_hypotheses_whose_windows_never_flip(name, full, pred
   assert np.median(e) < POSE_TOL and e[int(0.9 * (len(e) - 1))] < POSE_TOL, f'{name}: bulk of the never-flipped hypotheses after 5 full-gain iterations'
   assert e[-1] < 5 * POSE_TOL, f'{name}: worst never-flipped hypothesis after 5 full-gain iterations'
   # The claim above, measured: the fixture also holds the SAME five chained full-gain iterations with the oracle's
-  # network under torch.autocast('cpu', float16) - the precision the reference itself runs on the GPU (predict_pose_refine.py:190).  On the
-  # hypotheses whose windows flip in none of the three chains (fp32 oracle, fp16 oracle, HIP), the HIP chain must scatter around the fp32
-  # chain no more than 1.5 x as far as the reference's own fp16 chain does: median, 90th percentile and maximum.
+  # network under torch.autocast('cpu', float16) - the precision the reference itself runs on the GPU (predict_pose_refine.py:190).  Each
+  # fp16 chain (the reference's, the HIP path's) is judged against the fp32 chain on the hypotheses whose five windows it never flipped:
+  # (a) the HIP chain flips no more windows than the reference's fp16 chain does (a flip is the error crossing a rounding boundary);
+  # (b) where no window flips, the HIP chain scatters around the fp32 chain no more than 1.5 x as far as the reference's own fp16 chain:
+  # median, 90th percentile and maximum.  (The intersection of the two sets is reported; it is small - each chain flips its own windows.)
   key = f'{name}/poses_iter_ac16'
   if key in full:
     ac = full[key]
-    same3 = same.copy()
+    same_ac = np.ones(len(same), dtype=bool)
     for it in range(1, 6):
       ora_prev = c['poses0'] if it == 1 else want[it - 2]
       ac_prev = c['poses0'] if it == 1 else ac[it - 2]
-      same3 &= (window(ac_prev) == window(ora_prev)).reshape(len(same), -1).all(1)
-    assert same3.sum() >= len(same) // 5, 'too few hypotheses keep their windows in all three chains'
-    e_hip = np.sort(err[same3])
-    e_ref = np.sort(np.abs(ac[-1] - want[-1]).reshape(len(same), -1).max(1)[same3])
+      same_ac &= (window(ac_prev) == window(ora_prev)).reshape(len(same), -1).all(1)
+    e_hip = np.sort(err[same])
+    err_ref = np.abs(ac[-1] - want[-1]).reshape(len(same), -1).max(1)
+    e_ref = np.sort(err_ref[same_ac])
     q = lambda v: (float(np.median(v)), float(v[int(0.9 * (len(v) - 1))]), float(v[-1]))
     (mh, ph, xh), (mr, pr, xr) = q(e_hip), q(e_ref)
-    print(f'{name}: {int(same3.sum())} hypotheses without a window flip in any of the three chains: |hip - fp32| median {mh:.2e} p90 {ph:.2e} max {xh:.2e}; '
-          f'|reference fp16 - fp32| median {mr:.2e} p90 {pr:.2e} max {xr:.2e}; ratios {mh / mr:.2f} {ph / pr:.2f} {xh / xr:.2f}')
+    both = same & same_ac
+    print(f'{name}: windows never flipped: HIP chain {int(same.sum())} hypotheses, reference fp16 chain {int(same_ac.sum())}, both {int(both.sum())}. '
+          f'|hip - fp32| median {mh:.2e} p90 {ph:.2e} max {xh:.2e}; |reference fp16 - fp32| median {mr:.2e} p90 {pr:.2e} max {xr:.2e}; '
+          f'ratios {mh / mr:.2f} {ph / pr:.2f} {xh / xr:.2f}' +
+          (f'; on the {int(both.sum())} common ones: hip median {np.median(err[both]):.2e} max {err[both].max():.2e}, reference fp16 median '
+           f'{np.median(err_ref[both]):.2e} max {err_ref[both].max():.2e}' if both.sum() >= 5 else ''))
+    assert same_ac.sum() >= 10, 'too few hypotheses keep their windows in the reference fp16 chain for the comparison to mean anything'
+    assert same.sum() >= same_ac.sum(), f'{name}: the HIP chain flips more crop windows than the reference fp16 chain'
     assert mh <= 1.5 * mr and ph <= 1.5 * pr and xh <= 1.5 * xr, f'{name}: the HIP chain scatters further from the fp32 chain than 1.5 x the reference fp16 chain'
 
 
