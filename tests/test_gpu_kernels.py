@@ -746,9 +746,14 @@ def test_head_mlp_vs_fp32_reference(fp, n_hyp):
   err = float((got.cpu() - ref).abs().max())
   print(f'head_mlp M={M}: max |gsum - ref| = {err:.2e} on values of magnitude {float(ref.abs().max()):.1f}')
   assert err <= 2.5e-3 * float(ref.abs().max()) + 1e-3, err
-  if n_hyp > 1:
+  # a hypothesis' result does not depend on its place in the batch: bit-exact within a size class (1 .. 4 hypotheses run the 64-token form,
+  # larger batches the 128-token form: csrc/head_mlp.hip)
+  if n_hyp == 3:
     one = run(att[400:800].contiguous().cuda(), tok[400:800].contiguous().cuda(), 400)
     assert torch.equal(one, got[25:50])
+  elif n_hyp > 5:
+    part = run(att[400:2400].contiguous().cuda(), tok[400:2400].contiguous().cuda(), 2000)        # 5 hypotheses: tiles of 128 tokens cut elsewhere
+    assert torch.equal(part, got[25:150])
   # the three launches it replaces (tok_gemm.hip): same values up to the fp32 summation order of the LayerNorm statistics
   def lin(x_d, w, b, epi, relu, res_d, ln, out):
     check(lib().fp_token_linear_f16(fp['ctx'].handle, ptr(x_d), M, ptr(w.numpy()), ptr(b.numpy()), epi, relu, ptr(res_d) if res_d is not None else None,
@@ -783,7 +788,7 @@ def test_profiling_busy_time_is_the_union_of_launch_spans(fp):
   ctx.prof_enable(False)
   conv, lin = ctx.prof_read('conv3x3_halo'), ctx.prof_read('linear')
   ctx.prof_reset()
-  assert conv['launches'] == 3 * 12 and lin['launches'] == 3 * 4
+  assert conv['launches'] == 3 * 12 and lin['launches'] == 3 * 3          # (q | k | v of both heads: one launch; one fused MLP per head)
   assert conv['busy_ms'] > 0 and abs(conv['busy_ms'] - conv['total_ms']) <= 0.02 * conv['total_ms'] + 0.01
   assert 0 < lin['busy_ms'] <= lin['total_ms'] * 1.001 + 0.001
 
