@@ -23,7 +23,7 @@ def union_ns(v):
 
 # kernel classes of bench.py (all template variants of a class together: their launches overlap each other too)
 CLASSES = {'conv3x3_halo': ('conv3x3_halo_dma_kernel', 'conv3x3_s1_band_kernel'), 'conv3x3_s2': ('conv3x3_s2_kernel', 'conv_igemm2_kernelILi128ELi3'), 'conv7x7': 'stem7x7_kernel',
-           'linear': ('tok_gemm_kernel', 'head_mlp_kernel'), 'attention': '16attention_kernel', 'render': ('render_kernel', 'xform_vertices', 'classify_faces')}
+           'linear': ('tok_gemm_kernel', 'tok_qkv_kernel', 'head_mlp_kernel', 'head_mlp128_kernel'), 'attention': '16attention_kernel', 'render': ('render_kernel', 'xform_vertices', 'classify_faces')}
 steps = sum(len(v) for k, v in iv.items() if 'render_kernel<1' in k or 'render_kernelILi1' in k) / 6.0
 cls_rows = []
 for cname, pats in CLASSES.items():

@@ -5,7 +5,7 @@ FETCH_SIZE / WRITE_SIZE are reported in KB.  On gfx950 FETCH_SIZE counts a 128-b
 it is doubled here (MI355X_MICROARCH.md); WRITE_SIZE is taken as is.  Infinity-Cache hits are part of FETCH_SIZE, so the sum
 is fabric (L2-miss) traffic - an upper bound on HBM bytes."""
 import collections, csv, glob, json, os
-ROUND = os.environ.get('ROUND', 'r03')
+ROUND = os.environ.get('ROUND', 'r04')
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -18,7 +18,7 @@ def load(kind, counter):
   return agg
 
 
-HEAD_KERNELS = ('tok_gemm', 'head_mlp', 'attention_kernel', 'mean_head', 'vt_pad_zero', 'layernorm', 'ln_partial', 'token_mean', 'conv_igemm2_kernelILi128ELi1', 'conv_igemm2_kernelILi64ELi1')
+HEAD_KERNELS = ('tok_gemm', 'tok_qkv', 'head_mlp', 'attention_kernel', 'mean_head', 'vt_pad_zero', 'layernorm', 'ln_partial', 'token_mean', 'conv_igemm2_kernelILi128ELi1', 'conv_igemm2_kernelILi64ELi1')
 
 
 def chain_bytes(rows):
@@ -38,12 +38,12 @@ def head_chain(rows):
   now = chain_bytes(rows)
   before = {}
   prev = {}
-  for tag in ('r01', 'r02'):
+  for tag in ('r01', 'r02', 'r03'):
     old = os.path.join(REPO, 'profiles', tag + '_pmc_hbm_traffic.csv')
     if os.path.exists(old) and tag != ROUND:
       prev[tag] = chain_bytes([(r['kernel'], r['grid_threads'], r['launches'], r['FETCH_SIZE_KB_raw_mean'], r['fetch_MB_corrected_x2'], r['WRITE_SIZE_MB_mean'])
                                for r in csv.DictReader(open(old))])
-  before = prev.get('r02') or prev.get('r01') or {}
+  before = prev.get('r03') or prev.get('r02') or prev.get('r01') or {}
   js = {'unit': 'bytes per bench step (fetch x2-corrected + write), 11 head passes', 'this_round': now, 'this_round_total': sum(now.values()),
         'previous_rounds': {k: {'kernels': v, 'total': sum(v.values())} for k, v in prev.items()},
         'ratio_to_previous_round': (sum(now.values()) / sum(before.values())) if before else None}

@@ -5,7 +5,7 @@ the share of cycles its SIMDs' matrix pipes were busy.
   utilisation = MFMA_BUSY / (n_SIMD * GRBM_GUI_ACTIVE / 8), n_SIMD = 256 CUs x 4; effective clock = GRBM_GUI_ACTIVE / 8 / duration.
 Counter runs serialise the dispatches (no two-stream overlap), so durations here are those of kernels running ALONE."""
 import collections, csv, glob, json, os
-ROUND = os.environ.get('ROUND', 'r03')
+ROUND = os.environ.get('ROUND', 'r04')
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = os.path.join(REPO, 'gpurun_out', 'pmc_mfma')
 cc = glob.glob(d + '/**/*_counter_collection.csv', recursive=True)[0]
