@@ -488,7 +488,7 @@ def test_schedules_and_kernel_forms_are_bit_identical():
   one chain instead of two (FP_ONE_CHAIN=1), the trunk as one batch instead of two halves on two streams (FP_TRUNK_STREAMS=1), both heads
   on one stream (FP_HEADS_SERIAL=1), the 128 -> 128 layers on the general 3x3 kernel instead of the band form (FP_C128_BAND=0), the
   in-projections on the 64-token kernel instead of tok_qkv.hip (FP_QKV64=1), 512-pixel tiles only in the 3x3 kernel (FP_HALO_TAIL=0).  The
-  fused passes at 8, 40, 56 and 100 hypotheses (tests/tools/variant_digest.py) must print the digests of the default build."""
+  fused passes at 1, 2, 8, 40, 56 and 100 hypotheses (tests/tools/variant_digest.py) must print the digests of the default build."""
   import json, os, subprocess, sys
   script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'variant_digest.py')
 
