@@ -154,6 +154,22 @@ def bilateral_filter_depth(depth, radius=2, zfar=100, sigmaD=2, sigmaR=100000, d
   return out
 
 
+def depth_prefilter(depth, K, radius=2, depth_diff_thres=0.001, ratio_thres=0.8, zfar=100, sigmaD=2, sigmaR=100000, zfar_xyz=np.inf):
+  """The depth prelude of a tracking frame (src/estimater.py:256-260) in one launch (a build extension; not in the reference):
+  bilateral_filter_depth(erode_depth(depth, radius), radius) and depth2xyzmap_batch of the result with the float32 camera matrix.
+  Returns (depth (H,W), xyz_map (H,W,3)) on the device, bit-identical to the three calls chained."""
+  d = torch.as_tensor(depth, dtype=torch.float, device='cuda').contiguous()
+  ctx = _lib.Context.get(d.device)
+  H, W = d.shape
+  out = torch.empty_like(d)
+  xyz = torch.empty((H, W, 3), dtype=torch.float, device=d.device)
+  Kd, Kp = k_ptr(np.asarray(K.detach().cpu().numpy() if torch.is_tensor(K) else K, dtype=np.float32))
+  zf = float(zfar_xyz) if np.isfinite(zfar_xyz) else 3.0e38
+  check(lib().fp_depth_prefilter(ctx.handle, ptr(d), H, W, int(radius), float(depth_diff_thres), float(ratio_thres), float(zfar), float(zfar),
+                                 float(sigmaD), float(sigmaR), Kp, zf, ptr(out), ptr(xyz), stream_ptr(d.device)))
+  return out, xyz
+
+
 def depth2xyzmap(depth, K, uvs=None):
   """src/Utils.py:399-417: back-projection in float64 arithmetic, one rounding to float32, depth < 1 mm -> 0.
   Both input kinds run fp_depth2xyzmap_f64 on the device; a numpy image comes back as numpy (H,W,3) float32 like the

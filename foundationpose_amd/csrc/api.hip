@@ -434,6 +434,17 @@ extern "C" int fp_depth2xyzmap(fp_ctx *ctx, const float *d_depth, int H, int W, 
   return launch_depth2xyz(d_depth, H, W, K, zfar, d_xyz, (hipStream_t)stream);
 }
 
+extern "C" int fp_depth_prefilter(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
+                                  float zfar_erode, float zfar_bilateral, float sigmaD, float sigmaR, const double *K, float zfar_xyz,
+                                  float *d_depth_out, float *d_xyz, void *stream) {
+  FP_REQUIRE(ctx && d_depth && d_depth_out && d_xyz && K && H > 0 && W > 0, "fp_depth_prefilter: bad argument");
+  FP_REQUIRE(radius == 2, "fp_depth_prefilter: radius %d (the fused prelude is built for the radius 2 of src/estimater.py:256-257; "
+                          "other radii: fp_erode_depth, fp_bilateral_filter_depth, fp_depth2xyzmap)", radius);
+  FP_REQUIRE(d_depth != d_depth_out, "fp_depth_prefilter: in-place filtering is not possible (neighbouring workgroups read the input)");
+  return launch_depth_prefilter(d_depth, H, W, depth_diff_thres, ratio_thres, zfar_erode, zfar_bilateral, sigmaD, sigmaR, K, zfar_xyz, d_depth_out,
+                                d_xyz, (hipStream_t)stream);
+}
+
 extern "C" int fp_depth2xyzmap_f64(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float *d_xyz, void *stream) {
   FP_REQUIRE(ctx && d_depth && d_xyz && K && H > 0 && W > 0, "fp_depth2xyzmap_f64: bad argument");
   return launch_depth2xyz_f64(d_depth, H, W, K, d_xyz, (hipStream_t)stream);
@@ -559,6 +570,12 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
     // encodeA) and the observed side (crop window -> observed crop -> encodeA) are two chains on two streams up to the channel concat
     // (run_trunk): side B does not wait for the rasteriser.  Bit-identical to one chain.
     const bool two_sides = n_runs == 1 && N < fp_trunk_split_min() && !g_one_chain;
+    // One run of like objects (one camera, one mesh, one diameter): the heads' token means, the pose update and the crop windows of
+    // the next iteration are ONE launch behind the heads (refine_tail_kernel) instead of four.  Bit-identical (FP_TAIL_SPLIT=1: the four).
+    static const bool tail_split = getenv("FP_TAIL_SPLIT") != nullptr;
+    int first = 0;
+    while (first < n_obj && objs[first].n == 0) ++first;
+    const bool fused_tail = n_runs == 1 && !tail_split && fp_hyp_chunk(N) == N;
     for (int it = 0; it < iteration; ++it) {
       size_t voff = 0;
       int off = 0, k = 0;
@@ -571,7 +588,8 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
           const fp_object_batch &ob = objs[o];
           hipStream_t so = fo.stream_for(k++);
           float *p = d_poses + (size_t)off * 16;
-          FP_TRY(launch_crop_window_tf(p, cnt, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
+          if (!(fused_tail && it > 0))       // (from the second iteration on the previous pass' tail has written the windows)
+            FP_TRY(launch_crop_window_tf(p, cnt, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
           if (two_sides) ab.reset(new StreamFanout(ctx, s, 2));          // forks behind the crop windows
           const size_t rsb = (render_scratch_bytes(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu) + 255) & ~(size_t)255;
           int rc = render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
@@ -594,6 +612,23 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
         o = e;
       }
       FP_TRY(fo.join());
+      if (fused_tail) {
+        const fp_object_batch &ob = objs[first];
+        RefineTailArgs t;
+        memset(&t, 0, sizeof(t));
+        t.poses = d_poses;
+        t.trans_tanh = cfg->trans_rep_tanh;
+        t.tn0 = cfg->trans_normalizer[0], t.tn1 = cfg->trans_normalizer[1], t.tn2 = cfg->trans_normalizer[2];
+        t.rot_normalizer = cfg->rot_normalizer;
+        t.trans_scale = cfg->normalize_xyz ? (float)(ob.mesh_diameter / 2) : 1.f;
+        for (int i = 0; i < 9; ++i) t.K[i] = (float)ob.K[i];
+        t.resize = 160.f;
+        t.tf = tf, t.bbox = bbox;
+        t.next_window = it + 1 < iteration;
+        t.win = crop_window_k(ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160);
+        FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get(), &t));
+        continue;
+      }
       FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get()));     // ONE network pass for every object (joins `ab`)
       // pose update: one launch per run of objects with the same translation scale (one launch when they share a mesh)
       off = 0;

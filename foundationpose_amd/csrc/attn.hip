@@ -6,6 +6,7 @@
 // pose update: learning/training/predict_pose_refine.py:195-231 + pytorch3d so3_exp_map +
 // src/Utils.py:848-855.
 #include "common.h"
+#include "pose_math.h"
 
 #define AT_DH 128
 #define AT_TP 416    // padded token count of the transposed V image [b][4][128][416]
@@ -411,37 +412,89 @@ __device__ __forceinline__ float wave_sum(float v) {
 // mean_t(Linear(LN(x_t))) == Linear(mean_t LN(x_t))  (refine_network.py:90-91).  The LayerNorm itself runs in the epilogue of
 // linear2 (tok_gemm.hip, EPI_LNSUM), which leaves the sums of the normalised rows over groups of 16 tokens; one small workgroup
 // per hypothesis adds these partial rows in a fixed order (deterministic), applies gamma / beta and the output Linear.
+// (a) the 512 features of hypothesis b: partial rows added in a fixed order, gamma / beta applied -> meanv.  NH heads at once: every
+// load of every head is in flight before the first add (one memory round trip; a loop that waits per load was 25 of them)
+#define MH_MAXPARTS 32
+template <int NH>
+__device__ __forceinline__ void mean_head_rows(float (*meanv)[512], int b, const float *const *partial, int nparts, const float *const *gam,
+                                               const float *const *bet, int T) {
+  const int f = threadIdx.x;
+  float v[NH][MH_MAXPARTS];
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+#pragma unroll
+    for (int u = 0; u < MH_MAXPARTS; ++u) v[h][u] = partial[h][((size_t)b * nparts + min(u, nparts - 1)) * 512 + f];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < MH_MAXPARTS; ++u)
+      if (u < nparts) m += v[h][u];
+    meanv[h][f] = m * (1.f / (float)T) * gam[h][f] + bet[h][f];
+  }
+}
+// (b) output `o` of the head Linear by one wave
+__device__ __forceinline__ float mean_head_out(const float *meanv, const float *__restrict__ hw, const float *__restrict__ hb, int o, int lane) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += meanv[lane * 8 + i] * hw[(size_t)o * 512 + lane * 8 + i];
+  s = wave_sum(s);
+  return s + hb[o];
+}
+
 __global__ __launch_bounds__(512) void mean_head_kernel(const float *__restrict__ partial, int nparts, const float *__restrict__ gam,
                                                         const float *__restrict__ bet, int T, const float *__restrict__ hw,
                                                         const float *__restrict__ hb, int out_dim, float *__restrict__ out) {
-  __shared__ float meanv[512];
+  __shared__ float meanv[1][512];
   const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // every load of a feature's partials is issued before the first add (a rolled loop waits for each load in turn: at 25 parts
-  // that was 25 memory round trips, 26 us of a 1.4-ms tracking frame); the additions keep their fixed order
-  for (int f = threadIdx.x; f < 512; f += 512) {
-    float m = 0.f;
-    for (int q0 = 0; q0 < nparts; q0 += 8) {
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partial[((size_t)b * nparts + min(q0 + u, nparts - 1)) * 512 + f];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (q0 + u < nparts) m += v[u];
-    }
-    meanv[f] = m * (1.f / (float)T) * gam[f] + bet[f];
-  }
+  const float *p1[1] = {partial}, *g1[1] = {gam}, *b1[1] = {bet};
+  mean_head_rows<1>(meanv, b, p1, nparts, g1, b1, T);
   __syncthreads();
   for (int o = wave; o < out_dim; o += 8) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += meanv[lane * 8 + i] * hw[(size_t)o * 512 + lane * 8 + i];
-    s = wave_sum(s);
-    if (lane == 0) out[(size_t)b * out_dim + o] = s + hb[o];
+    const float r = mean_head_out(meanv[0], hw, hb, o, lane);
+    if (lane == 0) out[(size_t)b * out_dim + o] = r;
   }
+}
+
+// The tail of a refinement pass in ONE launch behind the join of the two heads: token mean + output Linear of the translation head
+// and of the rotation head (two mean_head_kernel launches), the pose update (pose_update_kernel) and - when another iteration
+// follows - its crop windows (crop_window_tf_kernel): four dependent launches of a few microseconds each, a workgroup per hypothesis.
+// Every piece is the building block's own device function: the results are those of the four launches bit for bit.
+__global__ __launch_bounds__(512) void refine_tail_kernel(RefineTailArgs a) {
+  __shared__ float meanv[2][512], delta[2][8];      // delta: this hypothesis' head outputs (also written to a.trans / a.rot)
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  mean_head_rows<2>(meanv, b, a.partial, a.nparts, a.gam, a.bet, a.T);
+  __syncthreads();
+  for (int o = wave; o < 3 + a.rot_dim; o += 8) {
+    const int h = o >= 3, oh = h ? o - 3 : o;
+    const float r = mean_head_out(meanv[h], a.hw[h], a.hb[h], oh, lane);
+    if (lane == 0) {
+      (h ? a.rot + (size_t)b * a.rot_dim : a.trans + (size_t)b * 3)[oh] = r;
+      delta[h][oh] = r;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  DeepimArgs dp;
+  dp.tf = a.tf;
+  dp.resize = a.resize;
+  for (int i = 0; i < 9; ++i) dp.K[i] = a.K[i];
+  pose_update_one(b, a.poses, delta[0], delta[1], a.rot_dim, a.trans_tanh, a.tn0, a.tn1, a.tn2, a.rot_normalizer, a.trans_scale, dp, a.poses);
+  if (a.next_window) crop_window_tf_one(b, a.poses, a.win, a.tf, a.bbox);
+}
+
+int launch_refine_tail(const RefineTailArgs &a, int N, hipStream_t s) {
+  FP_REQUIRE(a.rot_dim == 3 || a.rot_dim == 6, "refine tail: rot_dim must be 3 or 6");
+  FP_REQUIRE(a.nparts >= 1 && a.nparts <= MH_MAXPARTS, "refine tail: %d partial rows per hypothesis (at most %d)", a.nparts, MH_MAXPARTS);
+  if (N == 0) return FP_OK;
+  hipLaunchKernelGGL(refine_tail_kernel, dim3(N), dim3(512), 0, s, a);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
 }
 
 int launch_mean_head(const float *partial, int nparts, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
                      int out_dim, float *out, hipStream_t s) {
+  FP_REQUIRE(nparts >= 1 && nparts <= MH_MAXPARTS, "mean_head: %d partial rows per hypothesis (at most %d)", nparts, MH_MAXPARTS);
   if (Bn == 0) return FP_OK;
   hipLaunchKernelGGL(mean_head_kernel, dim3(Bn), dim3(512), 0, s, partial, nparts, g, b, T, hw, hb, out_dim, out);
   FP_CHECK_HIP(hipGetLastError());
@@ -655,98 +708,13 @@ int launch_argmax(const float *logits, int groups, int L, int32_t *out, hipStrea
   return FP_OK;
 }
 
-// pose update (predict_pose_refine.py:195-231): float32, mirrors oracle/predict.py:pose_update
-struct DeepimArgs {        // trans_rep='deepim' (predict_pose_refine.py:201-215): the crop transforms of this pass, the intrinsics, input_resize[0]
-  const float *tf;         // N x 9
-  float K[9];
-  float resize;
-};
-
-__device__ __forceinline__ void inv3x3(const float *m, float *o) {     // adjugate / determinant
-  const float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
-  const float id = 1.f / (m[0] * c00 + m[1] * c01 + m[2] * c02);
-  o[0] = c00 * id, o[1] = (m[2] * m[7] - m[1] * m[8]) * id, o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-  o[3] = c01 * id, o[4] = (m[0] * m[8] - m[2] * m[6]) * id, o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-  o[6] = c02 * id, o[7] = (m[1] * m[6] - m[0] * m[7]) * id, o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-}
-
+// pose update (predict_pose_refine.py:195-231): float32, mirrors oracle/predict.py:pose_update (pose_math.h)
 __global__ void pose_update_kernel(const float *__restrict__ poseA, const float *__restrict__ trans, const float *__restrict__ rot,
                                    int N, int rot_dim, int trans_tanh, float tn0, float tn1, float tn2, float rot_normalizer,
                                    float trans_scale, DeepimArgs dp, float *__restrict__ outp) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= N) return;
-  float A[12];                 // the pose is read completely before anything is written: outp may be poseA (in-place update)
-#pragma unroll
-  for (int i = 0; i < 12; ++i) A[i] = poseA[(size_t)b * 16 + i];
-  float td[3] = {trans[b * 3], trans[b * 3 + 1], trans[b * 3 + 2]};
-  if (trans_tanh == 1) {
-    td[0] = tanhf(td[0]) * tn0;
-    td[1] = tanhf(td[1]) * tn1;
-    td[2] = tanhf(td[2]) * tn2;
-  } else if (trans_tanh == 2) {
-    // deepim: the network predicts the shift of the projected centre in the crop (in units of the crop size) and the depth ratio
-    const float *tf = dp.tf + (size_t)b * 9, *K = dp.K;
-    const float cx = A[3], cy = A[7], cz = A[11];
-    const float z_pred = td[2] * cz;
-    float uvw[3];
-    for (int r = 0; r < 3; ++r) uvw[r] = K[r * 3] * cx + K[r * 3 + 1] * cy + K[r * 3 + 2] * cz;
-    const float u = uvw[0] / uvw[2], v = uvw[1] / uvw[2], w1 = uvw[2] / uvw[2];
-    const float uc = tf[0] * u + tf[1] * v + tf[2] * w1 + td[0] * dp.resize;      // uvA_crop + trans[:2] * input_resize[0]
-    const float vc = tf[3] * u + tf[4] * v + tf[5] * w1 + td[1] * dp.resize;
-    float ti[9], Ki[9];
-    inv3x3(tf, ti);
-    inv3x3(K, Ki);
-    const float up = ti[0] * uc + ti[1] * vc + ti[2], vp = ti[3] * uc + ti[4] * vc + ti[5];      // transform_pts(uv_pred_crop, tf^-1)
-    td[0] = (Ki[0] * up + Ki[1] * vp + Ki[2]) * z_pred - cx;
-    td[1] = (Ki[3] * up + Ki[4] * vp + Ki[5]) * z_pred - cy;
-    td[2] = (Ki[6] * up + Ki[7] * vp + Ki[8]) * z_pred - cz;
-  }
-  td[0] *= trans_scale;
-  td[1] *= trans_scale;
-  td[2] *= trans_scale;
-  float R[9];  // rot_mat_delta (already transposed as in the reference)
-  if (rot_dim == 3) {
-    const float x = tanhf(rot[b * 3]) * rot_normalizer, y = tanhf(rot[b * 3 + 1]) * rot_normalizer,
-                z = tanhf(rot[b * 3 + 2]) * rot_normalizer;
-    const float nrm = fmaxf(x * x + y * y + z * z, 1e-4f);
-    const float th = sqrtf(nrm), ith = 1.f / th;
-    const float f1 = ith * sinf(th), f2 = ith * ith * (1.f - cosf(th));
-    const float Kx[9] = {0.f, -z, y, z, 0.f, -x, -y, x, 0.f};
-    float K2[9];
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) K2[r * 3 + c] = Kx[r * 3] * Kx[c] + Kx[r * 3 + 1] * Kx[3 + c] + Kx[r * 3 + 2] * Kx[6 + c];
-    float E[9];
-    for (int i = 0; i < 9; ++i) E[i] = f1 * Kx[i] + f2 * K2[i] + ((i % 4 == 0) ? 1.f : 0.f);
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) R[r * 3 + c] = E[c * 3 + r];  // .permute(0,2,1)
-  } else {
-    const float *d6 = rot + (size_t)b * 6;
-    float a1[3] = {d6[0], d6[1], d6[2]}, a2[3] = {d6[3], d6[4], d6[5]};
-    float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
-    float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
-    float dp = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
-    float b2[3] = {a2[0] - dp * b1[0], a2[1] - dp * b1[1], a2[2] - dp * b1[2]};
-    float n2 = fmaxf(sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]), 1e-12f);
-    b2[0] /= n2;
-    b2[1] /= n2;
-    b2[2] /= n2;
-    float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
-    // rows (b1,b2,b3) then transposed
-    for (int c = 0; c < 3; ++c) {
-      R[c * 3 + 0] = b1[c];
-      R[c * 3 + 1] = b2[c];
-      R[c * 3 + 2] = b3[c];
-    }
-  }
-  float *O = outp + (size_t)b * 16;
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c) O[r * 4 + c] = R[r * 3] * A[c] + R[r * 3 + 1] * A[4 + c] + R[r * 3 + 2] * A[8 + c];
-    O[r * 4 + 3] = A[r * 4 + 3] + td[r];
-  }
-  O[12] = 0.f;
-  O[13] = 0.f;
-  O[14] = 0.f;
-  O[15] = 1.f;
+  pose_update_one(b, poseA, trans + (size_t)b * 3, rot + (size_t)b * rot_dim, rot_dim, trans_tanh, tn0, tn1, tn2, rot_normalizer, trans_scale, dp, outp);
 }
 
 int launch_pose_update(const float *poseA, const float *trans, const float *rot, int N, int rot_dim, int trans_tanh, float tn0,

@@ -151,7 +151,12 @@ struct StreamFanout {
 // ab->stream_for(0), side A's on `s`; nullptr: one chain); batches below fp_trunk_split_min() hypotheses only (larger ones are cut in two by hypotheses)
 struct fp_net;
 int fp_trunk_split_min();
-int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab);
+struct RefineTailArgs;
+int fp_hyp_chunk(int n_total);             // hypotheses per network pass (FP_CHUNK; default: the whole batch)
+// `tail` (optional; pose / window fields filled by the caller, head fields by the forward pass): the heads' token means, the pose update
+// and the next crop windows as ONE launch behind the join of the heads (refine_tail_kernel) instead of two mean_head launches here
+int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab,
+                         RefineTailArgs *tail = nullptr);
 int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, hipStream_t s, StreamFanout *ab);
 
 // profiling hooks (events on the launch stream)
@@ -295,6 +300,25 @@ int launch_small_linear(const float *x, const float *w, const float *wt, const f
 int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s);
 int launch_argmax(const float *logits, int groups, int L, int32_t *out, hipStream_t s);
 // trans_tanh: 0 raw, 1 tanh * trans_normalizer, 2 trans_rep='deepim' (needs tf N x 9, K, resize = input_resize[0])
+// The tail of a refinement pass as one launch (attn.hip: refine_tail_kernel): both heads' token mean + output Linear, the pose update in
+// place and, with `next_window`, the crop windows of the next iteration (tf / bbox overwritten; the deepim branch reads tf first)
+struct CropWindowK {             // intrinsics as float, radius = diameter * crop_ratio / 2, output size (crop_window_tf_one, pose_math.h)
+  float k00, k01, k02, k10, k11, k12, k20, k21, k22, radius, ow, oh;
+};
+CropWindowK crop_window_k(const double *K, double crop_ratio, double diameter, int ow, int oh);
+struct RefineTailArgs {
+  const float *partial[2], *gam[2], *bet[2], *hw[2], *hb[2];      // per head: group sums of linear2's LayerNorm rows, ln2 gamma / beta, head Linear
+  int nparts, T, rot_dim;
+  float *trans, *rot;            // (N,3), (N,rot_dim): the heads' outputs (API outputs of the pass)
+  float *poses;                  // (N,4,4) updated in place
+  int trans_tanh;
+  float tn0, tn1, tn2, rot_normalizer, trans_scale;
+  float K[9], resize;            // deepim
+  float *tf, *bbox;              // (N,9), (N,4)
+  int next_window;
+  CropWindowK win;
+};
+int launch_refine_tail(const RefineTailArgs &a, int N, hipStream_t s);
 int launch_pose_update(const float *poseA, const float *trans, const float *rot, int N, int rot_dim, int trans_tanh,
                        float tn0, float tn1, float tn2, float rot_normalizer, float trans_scale, float *out, hipStream_t s,
                        const float *tf = nullptr, const double *K = nullptr, float resize = 160.f);
@@ -349,5 +373,7 @@ int launch_crop_observed(const CropArgs &a, hipStream_t s);
 int launch_erode(const float *d, int H, int W, int radius, float diff_thres, float ratio_thres, float zfar, float *out, hipStream_t s);
 int launch_bilateral(const float *d, int H, int W, int radius, float zfar, float sigmaD, float sigmaR, float *out, hipStream_t s);
 int launch_depth2xyz(const float *d, int H, int W, const double *K, float zfar, float *xyz, hipStream_t s);
+int launch_depth_prefilter(const float *d, int H, int W, float diff_thres, float ratio_thres, float zfar_e, float zfar_b, float sigmaD,
+                           float sigmaR, const double *K, float zfar_x, float *out, float *xyz, hipStream_t s);
 int launch_depth2xyz_f64(const float *d, int H, int W, const double *K, float *xyz, hipStream_t s);
 int launch_mask_depth_stats(const float *d, const unsigned char *mask, int H, int W, float min_depth, int *out6, float *median, hipStream_t s);

@@ -238,6 +238,105 @@ int launch_depth2xyz(const float *d, int H, int W, const double *K, float zfar, 
   return FP_OK;
 }
 
+// The tracking prelude of a frame in ONE launch: erode_depth -> bilateral_filter_depth -> depth2xyzmap_batch (radius 2 both,
+// src/estimater.py:256-260).  As three launches a 640x480 frame costs 10 + 23 + 3 us, nearly all of it the latency of 25 + 50
+// dependent global loads per pixel behind data-dependent branches.  Here a workgroup stages the raw depth of its 32x8 tile plus a
+// 4-pixel border in LDS, writes the eroded depth of the tile plus a 2-pixel border to LDS, and filters from there.  The arithmetic
+// and its order (columns outer, rows inner) are those of the three kernels above: the outputs are theirs bit for bit.
+#define PF_R 2
+#define PF_TW 32
+#define PF_TH 8
+__global__ __launch_bounds__(PF_TW *PF_TH) void depth_prefilter_kernel(const float *__restrict__ depth, int H, int W, float diff_thres,
+                                                                       float ratio_thres, float zfar_e, float zfar_b, float sigmaD, float sigmaR,
+                                                                       float fx, float fy, float cx, float cy, float zfar_x,
+                                                                       float *__restrict__ out, float *__restrict__ xyz) {
+  constexpr int R = PF_R, RW = PF_TW + 4 * R, RH = PF_TH + 4 * R, EW = PF_TW + 2 * R, EH = PF_TH + 2 * R;
+  __shared__ float raw[RH][RW + 1], er[EH][EW + 1];
+  const float OUTSIDE = -__builtin_inff();            // marks pixels beyond the image (the loops of the three kernels skip them)
+  const int tid = threadIdx.y * PF_TW + threadIdx.x, w0 = blockIdx.x * PF_TW, h0 = blockIdx.y * PF_TH;
+  for (int i = tid; i < RH * RW; i += PF_TW * PF_TH) {
+    const int r = i / RW, c = i - r * RW, h = h0 - 2 * R + r, w = w0 - 2 * R + c;
+    raw[r][c] = (h >= 0 && h < H && w >= 0 && w < W) ? depth[(size_t)h * W + w] : OUTSIDE;
+  }
+  __syncthreads();
+  for (int i = tid; i < EH * EW; i += PF_TW * PF_TH) {
+    const int r = i / EW, c = i - r * EW;             // eroded pixel (h0 - R + r, w0 - R + c) = raw[r + R][c + R]
+    const float d_ori = raw[r + R][c + R];
+    float v = OUTSIDE;
+    if (d_ori != OUTSIDE) {
+      float bad = 0.f, total = 0.f;
+#pragma unroll
+      for (int du = 0; du <= 2 * R; ++du)
+#pragma unroll
+        for (int dv = 0; dv <= 2 * R; ++dv) {
+          const float cur = raw[r + dv][c + du];
+          if (cur == OUTSIDE) continue;
+          total += 1.f;
+          if (cur < 0.001f || cur >= zfar_e || fabsf(cur - d_ori) > diff_thres) bad += 1.f;
+        }
+      v = (__fdiv_rn(bad, total) > ratio_thres) ? 0.f : d_ori;
+    }
+    er[r][c] = v;
+  }
+  __syncthreads();
+  const int w = w0 + threadIdx.x, h = h0 + threadIdx.y;
+  if (w >= W || h >= H) return;
+  const int r = threadIdx.y, c = threadIdx.x;          // this pixel = er[r + R][c + R]
+  float mean_depth = 0.f;
+  int num_valid = 0;
+#pragma unroll
+  for (int du = 0; du <= 2 * R; ++du)
+#pragma unroll
+    for (int dv = 0; dv <= 2 * R; ++dv) {
+      const float cur = er[r + dv][c + du];             // (OUTSIDE fails cur >= 0.001 like a skipped pixel)
+      if (cur >= 0.001f && cur < zfar_b) {
+        num_valid += 1;
+        mean_depth = __fadd_rn(mean_depth, cur);
+      }
+    }
+  float res = 0.f;
+  if (num_valid > 0) {
+    mean_depth = __fdiv_rn(mean_depth, (float)num_valid);
+    const float dc = er[r + R][c + R];
+    float sum_w = 0.f, sum = 0.f;
+    const float den_d = __fmul_rn(__fmul_rn(2.f, sigmaD), sigmaD), den_r = __fmul_rn(__fmul_rn(2.f, sigmaR), sigmaR);
+#pragma unroll
+    for (int du = 0; du <= 2 * R; ++du)
+#pragma unroll
+      for (int dv = 0; dv <= 2 * R; ++dv) {
+        const float cur = er[r + dv][c + du];
+        if (cur >= 0.001f && cur < zfar_b && fabsf(cur - mean_depth) < 0.01f) {
+          const float sp = __fdiv_rn(-(float)((du - R) * (du - R) + (dv - R) * (dv - R)), den_d);
+          const float df = __fsub_rn(dc, cur);
+          const float rg = __fdiv_rn(__fmul_rn(df, df), den_r);
+          const float wt = expf(__fsub_rn(sp, rg));
+          sum_w = __fadd_rn(sum_w, wt);
+          sum = __fadd_rn(sum, __fmul_rn(wt, cur));
+        }
+      }
+    if (sum_w > 0.f) res = __fdiv_rn(sum, sum_w);
+  }
+  out[(size_t)h * W + w] = res;
+  float o[3] = {0.f, 0.f, 0.f};
+  if (!(res < 0.001f) && !(res > zfar_x)) {
+    o[0] = __fdiv_rn(__fmul_rn(__fsub_rn((float)w, cx), res), fx);
+    o[1] = __fdiv_rn(__fmul_rn(__fsub_rn((float)h, cy), res), fy);
+    o[2] = res;
+  }
+  const size_t q = ((size_t)h * W + w) * 3;
+  xyz[q] = o[0];
+  xyz[q + 1] = o[1];
+  xyz[q + 2] = o[2];
+}
+
+int launch_depth_prefilter(const float *d, int H, int W, float diff_thres, float ratio_thres, float zfar_e, float zfar_b, float sigmaD,
+                           float sigmaR, const double *K, float zfar_x, float *out, float *xyz, hipStream_t s) {
+  hipLaunchKernelGGL(depth_prefilter_kernel, dim3((W + PF_TW - 1) / PF_TW, (H + PF_TH - 1) / PF_TH), dim3(PF_TW, PF_TH), 0, s, d, H, W, diff_thres,
+                     ratio_thres, zfar_e, zfar_b, sigmaD, sigmaR, (float)K[0], (float)K[4], (float)K[2], (float)K[5], zfar_x, out, xyz);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
 // depth2xyzmap (src/Utils.py:399-417): the host function of the reference works in float64 (numpy promotes the float32 depth
 // against the float64 K) and rounds once to float32; depth < 0.001 -> 0.
 __global__ void depth2xyz_f64_kernel(const float *__restrict__ depth, int H, int W, double fx, double fy, double cx, double cy,

@@ -42,7 +42,7 @@ struct fp_net {
 };
 
 // Hypotheses per network pass: the whole batch.  FP_CHUNK=n (environment, experiments only) splits it.
-static int fp_hyp_chunk(int n_total) {
+int fp_hyp_chunk(int n_total) {
   static int env = getenv("FP_CHUNK") ? atoi(getenv("FP_CHUNK")) : -1;
   int ch = env >= 0 ? env : 0;
   if (ch <= 0 || ch > n_total) ch = n_total;
@@ -501,7 +501,8 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
 }
 
 // `ab`: side B of the network input is being produced on ab->stream_for(0), side A on `s` (the fused passes of api.hip): run_trunk
-int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab) {
+int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab,
+                         RefineTailArgs *tail) {
   FP_REQUIRE(ctx && net && d_net_in && d_trans && d_rot, "fp_refine_forward: null argument");
   FP_REQUIRE(net->kind == FP_NET_REFINE, "fp_refine_forward: not a RefineNet");
   FP_REQUIRE(N >= 0, "fp_refine_forward: N<0");
@@ -510,6 +511,7 @@ int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, i
   const int CH = fp_hyp_chunk(NT);
   FP_TRY(fp_arena_ensure(ctx, fp_arena_inner_bytes(CH)));
   const size_t mark = ctx->arena.off;
+  if (CH != NT) tail = nullptr;                       // (hypothesis chunks: the building-block launches)
   auto body = [&](int s0, int N) -> int {
     f16 *tok = nullptr;
     const f16 *in = (const f16 *)d_net_in;
@@ -550,9 +552,19 @@ int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, i
       a.g1 = H.ln1g, a.be1 = H.ln1b;
       a.gsum = gsum[h];
       FP_TRY(launch_head_mlp(ctx, a, sh));
-      FP_TRY(launch_mean_head(gsum[h], 25, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], sh));
+      if (!tail) FP_TRY(launch_mean_head(gsum[h], 25, H.ln2g, H.ln2b, N, 400, H.hw, H.hb, H.out_dim, outs[h], sh));
     }
     FP_TRY(fo.join());
+    if (tail) {
+      for (int h = 0; h < 2; ++h) {
+        const HeadW &H = net->heads[h];
+        tail->partial[h] = gsum[h], tail->gam[h] = H.ln2g, tail->bet[h] = H.ln2b, tail->hw[h] = H.hw, tail->hb[h] = H.hb;
+      }
+      tail->nparts = 25, tail->T = 400, tail->rot_dim = net->heads[1].out_dim;
+      tail->trans = outs[0], tail->rot = outs[1];
+      FP_REQUIRE(net->heads[0].out_dim == 3, "refine tail: translation head of %d outputs", net->heads[0].out_dim);
+      FP_TRY(launch_refine_tail(*tail, N, s));
+    }
     return FP_OK;
   };
   // hypothesis chunks (FP_CHUNK, default: the whole batch in one pass) reuse the SAME arena addresses.  Chunking to keep

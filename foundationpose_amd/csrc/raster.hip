@@ -29,6 +29,7 @@
 // Triangles that straddle the camera plane are rasterised in homogeneous coordinates (below).
 // The arithmetic is mirrored 1:1 by oracle/raster_c.c.
 #include "common.h"
+#include "pose_math.h"
 #include <cstdlib>
 
 #define RB_THREADS 1024
@@ -839,59 +840,21 @@ int launch_render(fp_ctx *ctx, const RenderArgs &a, hipStream_t s) {
 // (predict_pose_refine.py:44-45).  float32, left-to-right, no FMA contraction: mirrors
 // oracle/geometry.py:compute_crop_window_tf_batch.
 // ----------------------------------------------------------------------------------------------
-__global__ void crop_window_tf_kernel(const float *__restrict__ poses, int N, float k00, float k01, float k02, float k10, float k11,
-                                      float k12, float k20, float k21, float k22, float radius, float ow, float oh, float *tf,
-                                      float *bbox) {
+__global__ void crop_window_tf_kernel(const float *__restrict__ poses, int N, CropWindowK c, float *tf, float *bbox) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= N) return;
-  const float *p = poses + (size_t)b * 16;
-  float tx = p[3], ty = p[7], tz = p[11];
-  float offx[5] = {0.f, radius, -radius, 0.f, 0.f};
-  float offy[5] = {0.f, 0.f, 0.f, radius, -radius};
-  float u[5], v[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    float x = __fadd_rn(tx, offx[k]), y = __fadd_rn(ty, offy[k]), z = __fadd_rn(tz, 0.f);
-    float pu = __fadd_rn(__fadd_rn(__fmul_rn(k00, x), __fmul_rn(k01, y)), __fmul_rn(k02, z));
-    float pv = __fadd_rn(__fadd_rn(__fmul_rn(k10, x), __fmul_rn(k11, y)), __fmul_rn(k12, z));
-    float pw = __fadd_rn(__fadd_rn(__fmul_rn(k20, x), __fmul_rn(k21, y)), __fmul_rn(k22, z));
-    u[k] = __fdiv_rn(pu, pw);
-    v[k] = __fdiv_rn(pv, pw);
-  }
-  float rad = 0.f;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    rad = fmaxf(rad, fabsf(__fsub_rn(u[k], u[0])));
-    rad = fmaxf(rad, fabsf(__fsub_rn(v[k], v[0])));
-  }
-  float left = rintf(__fsub_rn(u[0], rad)), right = rintf(__fadd_rn(u[0], rad));
-  float top = rintf(__fsub_rn(v[0], rad)), bottom = rintf(__fadd_rn(v[0], rad));
-  // `out_size[0]/(right-left)` is int / Tensor in the reference -> Tensor.__rtruediv__ = reciprocal() * scalar
-  float sx = __fmul_rn(__fdiv_rn(1.f, __fsub_rn(right, left)), ow), sy = __fmul_rn(__fdiv_rn(1.f, __fsub_rn(bottom, top)), oh);
-  float t02 = __fmul_rn(sx, -left), t12 = __fmul_rn(sy, -top);
-  float *T = tf + (size_t)b * 9;
-  T[0] = sx; T[1] = 0.f; T[2] = t02;
-  T[3] = 0.f; T[4] = sy; T[5] = t12;
-  T[6] = 0.f; T[7] = 0.f; T[8] = 1.f;
-  if (bbox) {
-    // tf^-1 applied to (0,0) and (ow-1,oh-1): inverse of [[sx,0,t02],[0,sy,t12],[0,0,1]]
-    float i00 = __fdiv_rn(1.f, sx), i11 = __fdiv_rn(1.f, sy);
-    float i02 = -__fdiv_rn(t02, sx), i12 = -__fdiv_rn(t12, sy);
-    float *B = bbox + (size_t)b * 4;
-    B[0] = i02;
-    B[1] = i12;
-    B[2] = __fadd_rn(__fmul_rn(i00, ow - 1.f), i02);
-    B[3] = __fadd_rn(__fmul_rn(i11, oh - 1.f), i12);
-  }
+  crop_window_tf_one(b, poses, c, tf, bbox);
+}
+
+CropWindowK crop_window_k(const double *K, double crop_ratio, double diameter, int ow, int oh) {
+  return CropWindowK{(float)K[0], (float)K[1], (float)K[2], (float)K[3], (float)K[4], (float)K[5], (float)K[6], (float)K[7], (float)K[8],
+                     (float)(diameter * crop_ratio / 2.0), (float)ow, (float)oh};
 }
 
 int launch_crop_window_tf(const float *poses, int N, const double *K, double crop_ratio, double diameter, int ow, int oh, float *tf,
                           float *bbox, hipStream_t s) {
   if (N == 0) return FP_OK;
-  float radius = (float)(diameter * crop_ratio / 2.0);
-  hipLaunchKernelGGL(crop_window_tf_kernel, dim3((N + 63) / 64), dim3(64), 0, s, poses, N, (float)K[0], (float)K[1], (float)K[2],
-                     (float)K[3], (float)K[4], (float)K[5], (float)K[6], (float)K[7], (float)K[8], radius, (float)ow, (float)oh, tf,
-                     bbox);
+  hipLaunchKernelGGL(crop_window_tf_kernel, dim3((N + 63) / 64), dim3(64), 0, s, poses, N, crop_window_k(K, crop_ratio, diameter, ow, oh), tf, bbox);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -86,6 +86,14 @@ class FoundationPose:
     tf[:3, 3] = -torch.as_tensor(self.model_center, device='cuda', dtype=torch.float)
     return tf
 
+  def _tf_to_centered_cached(self):
+    """get_tf_to_centered_mesh() built once per model centre (a tracking frame is ~1 ms: the three small launches that build the
+    matrix are worth keeping out of it)."""
+    key = np.asarray(self.model_center, dtype=np.float64).tobytes()
+    if getattr(self, '_tf_centered_key', None) != key:
+      self._tf_centered, self._tf_centered_key = self.get_tf_to_centered_mesh(), key
+    return self._tf_centered
+
   def to_device(self, s='cuda:0'):
     for name, value in list(vars(self).items()):
       if torch.is_tensor(value):
@@ -194,22 +202,25 @@ class FoundationPose:
   def _track_frame(self, rgb, depth, K, pose_in, iteration, n_hyp, sigmas):
     """Device work of one tracking frame, free of host synchronisation (so that it can be captured in a hipGraph): depth
     filtering, back-projection, refinement of the previous pose (n_hyp == 1: src/estimater.py:256-266) or of n_hyp seeded
-    perturbations of it + scoring.  Returns (new pose (4,4), poses, scores, best_id) - device tensors."""
+    perturbations of it + scoring.  Returns (new pose (4,4), poses, scores, best_id, new pose @ get_tf_to_centered_mesh()) -
+    device tensors."""
     from .tracking import tracking_hypotheses
     rgb = rgb.to(torch.float)
-    depth = U.bilateral_filter_depth(U.erode_depth(depth, radius=2, device='cuda'), radius=2, device='cuda')
-    # the reference back-projects with the float32 camera matrix here (depth2xyzmap_batch on a float tensor of K)
-    xyz_map = U.depth2xyzmap_batch(depth[None], np.asarray(K, dtype=np.float32)[None], zfar=np.inf)[0]
+    # erode_depth -> bilateral_filter_depth -> depth2xyzmap_batch (src/estimater.py:256-260; the reference back-projects with the
+    # float32 camera matrix here), one launch
+    depth, xyz_map = U.depth_prefilter(depth, K, radius=2)
     shared = dict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K, glctx=self.glctx, mesh_diameter=self.diameter)
     if n_hyp == 1:
       pose, _ = self.refiner.predict(ob_in_cams=pose_in.reshape(-1, 4, 4), normal_map=None, xyz_map=xyz_map, iteration=iteration,
                                      get_vis=False, **shared)
-      return pose.reshape(4, 4), None, None, None
+      pose = pose.reshape(4, 4)
+      return pose, None, None, None, pose @ self._tf_to_centered_cached()
     hyp = tracking_hypotheses(pose_in.reshape(4, 4), n_hyp, *sigmas)
     refined, _ = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
     scores, _ = self.scorer.predict(ob_in_cams=refined, normal_map=None, **shared)
     best = scores.argmax()
-    return refined.index_select(0, best.reshape(1))[0], refined, scores, best      # (indexing by a 0-d tensor would synchronise)
+    pose = refined.index_select(0, best.reshape(1))[0]                             # (indexing by a 0-d tensor would synchronise)
+    return pose, refined, scores, best, pose @ self._tf_to_centered_cached()
 
   def enable_track_graph(self, on=True):
     """Replay a tracking frame as ONE hipGraph: at 1 .. 64 hypotheses a frame is ~100 kernels of one workgroup round or less
@@ -247,7 +258,8 @@ class FoundationPose:
     st['depth'].copy_(depth)
     st['pose'].copy_(pose_in)
     entry['graph'].replay()
-    return tuple(None if t is None else t.clone() for t in st['out'])      # the static outputs are overwritten by the next replay
+    out = st['out']      # the static outputs are overwritten by the next replay: cloned, except the last (the caller copies it to the host at once)
+    return tuple(None if t is None else t.clone() for t in out[:-1]) + (out[-1],)
 
   def track_one(self, rgb, depth, K, iteration, extra={}):
     """src/estimater.py:250-268: refine the previous pose against a new frame (no scoring)."""
@@ -255,7 +267,7 @@ class FoundationPose:
       logging.info("Please init pose by register first")
       raise RuntimeError
     pose_in = self.pose_last
-    pose, _, _, _ = self._run_frame(rgb, depth, K, iteration, 1, None)
+    pose, _, _, _, pose_of_mesh = self._run_frame(rgb, depth, K, iteration, 1, None)
     if self.debug >= 2:            # src/estimater.py:263-266: the refiner's canvas for this frame (debug only: the frame is refined a second time for it)
       d = U.bilateral_filter_depth(U.erode_depth(torch.as_tensor(depth, device='cuda', dtype=torch.float), radius=2, device='cuda'), radius=2, device='cuda')
       xyz_map = U.depth2xyzmap_batch(d[None], np.asarray(K, dtype=np.float32)[None], zfar=np.inf)[0]
@@ -263,7 +275,7 @@ class FoundationPose:
                                              mesh_diameter=self.diameter, ob_in_cams=pose_in.reshape(-1, 4, 4), normal_map=None, xyz_map=xyz_map,
                                              iteration=iteration, get_vis=True)
     self.pose_last = pose
-    return (pose @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)
+    return pose_of_mesh.data.cpu().numpy().reshape(4, 4)      # src/estimater.py:268: pose @ get_tf_to_centered_mesh() (inside the frame's graph)
 
   def track_multi(self, rgb, depth, K, iteration, n_hypotheses=64, trans_sigma=0.01, rot_sigma_deg=5.0, extra={}):
     """Multi-hypothesis tracking (BASELINE.json configs[4]; a build extension, the reference's track_one refines one pose
@@ -273,7 +285,7 @@ class FoundationPose:
     if self.pose_last is None:
       logging.info("Please init pose by register first")
       raise RuntimeError
-    pose, self.poses, self.scores, self.best_id = self._run_frame(rgb, depth, K, iteration, int(n_hypotheses),
-                                                                  (float(trans_sigma), float(rot_sigma_deg)))
+    pose, self.poses, self.scores, self.best_id, pose_of_mesh = self._run_frame(rgb, depth, K, iteration, int(n_hypotheses),
+                                                                                (float(trans_sigma), float(rot_sigma_deg)))
     self.pose_last = pose
-    return (pose @ self.get_tf_to_centered_mesh()).data.cpu().numpy().reshape(4, 4)
+    return pose_of_mesh.data.cpu().numpy().reshape(4, 4)

@@ -293,6 +293,33 @@ def test_depth_filters(sc, fp):
   assert U.erode_depth(z, radius=2).max() == 0 and U.bilateral_filter_depth(z, radius=2).max() == 0
 
 
+@pytest.mark.parametrize('hw', [(480, 640), (61, 83), (5, 7), (8, 32), (9, 33)])
+def test_depth_prefilter_equals_the_three_kernels_chained(sc, fp, hw):
+  """Utils.depth_prefilter (one launch, LDS tiles: the prelude of a tracking frame) against erode_depth -> bilateral_filter_depth ->
+  depth2xyzmap_batch on the device: bit-identical depth and xyz map, on images with holes, values beyond zfar, borders that cut
+  the 32x8 tiles, and images smaller than one tile."""
+  U = fp['U']
+  H, W = hw
+  rs = np.random.RandomState(H * 1000 + W)
+  d = sc['depth'][:H, :W].copy() if (H, W) != (480, 640) else sc['depth'].copy()
+  d = np.ascontiguousarray(d) + (rs.uniform(-1, 1, d.shape) * np.where(np.arange(W) < W // 2, 0.002, 0.01)[None]).astype(np.float32)   # (noise: erosion and the 1 cm gate both bite)
+  d[rs.uniform(size=d.shape) < 0.05] = 0.0
+  d[rs.uniform(size=d.shape) < 0.02] = 150.0
+  d[:, W // 2] = np.where(rs.uniform(size=H) < 0.5, 0.0005, d[:, W // 2])
+  K32 = np.asarray(sc['K'], dtype=np.float32)
+  dt = torch.from_numpy(d).cuda()
+  chain_d = U.bilateral_filter_depth(U.erode_depth(dt, radius=2, device='cuda'), radius=2, device='cuda')
+  chain_x = U.depth2xyzmap_batch(chain_d[None], K32[None], zfar=np.inf)[0]
+  fused_d, fused_x = U.depth_prefilter(dt, sc['K'], radius=2)
+  assert fused_d.shape == (H, W) and fused_x.shape == (H, W, 3)
+  assert torch.equal(fused_d, chain_d), int((fused_d != chain_d).sum())
+  assert torch.equal(fused_x, chain_x)
+  if H * W > 1000:
+    assert float((fused_d > 0).float().mean()) > 0.2 and float((fused_d == 0).float().mean()) > 0.02      # (both outcomes of the erosion occur)
+  with pytest.raises(RuntimeError, match='radius'):
+    U.depth_prefilter(dt, sc['K'], radius=3)
+
+
 def test_pose_update(fp):
   from oracle import predict as OP
   from foundationpose_amd._lib import check, lib, ptr, stream_ptr

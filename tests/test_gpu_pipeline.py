@@ -487,7 +487,8 @@ def test_schedules_and_kernel_forms_are_bit_identical():
   """Schedules and kernel forms that claim bit-identical results (one process each: the knobs are read once): the two sides of encodeA as
   one chain instead of two (FP_ONE_CHAIN=1), the trunk as one batch instead of two halves on two streams (FP_TRUNK_STREAMS=1), both heads
   on one stream (FP_HEADS_SERIAL=1), the 128 -> 128 layers on the general 3x3 kernel instead of the band form (FP_C128_BAND=0), the
-  in-projections on the 64-token kernel instead of tok_qkv.hip (FP_QKV64=1), 512-pixel tiles only in the 3x3 kernel (FP_HALO_TAIL=0).  The
+  in-projections on the 64-token kernel instead of tok_qkv.hip (FP_QKV64=1), 512-pixel tiles only in the 3x3 kernel (FP_HALO_TAIL=0), the tail
+  of a refinement pass (token means of both heads, pose update, next crop windows) as four launches instead of one (FP_TAIL_SPLIT=1).  The
   fused passes at 1, 2, 8, 40, 56 and 100 hypotheses (tests/tools/variant_digest.py) must print the digests of the default build."""
   import json, os, subprocess, sys
   script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'variant_digest.py')
@@ -498,5 +499,5 @@ def test_schedules_and_kernel_forms_are_bit_identical():
     return json.loads([l for l in r.stdout.splitlines() if l.startswith('DIGEST ')][-1][7:])
   ref = digests({})
   assert len(set(ref.values())) == len(ref)
-  for knobs in ({'FP_ONE_CHAIN': '1'}, {'FP_TRUNK_STREAMS': '1', 'FP_HEADS_SERIAL': '1'}, {'FP_C128_BAND': '0', 'FP_QKV64': '1'}, {'FP_HALO_TAIL': '0'}):
+  for knobs in ({'FP_ONE_CHAIN': '1'}, {'FP_TRUNK_STREAMS': '1', 'FP_HEADS_SERIAL': '1'}, {'FP_C128_BAND': '0', 'FP_QKV64': '1'}, {'FP_HALO_TAIL': '0', 'FP_TAIL_SPLIT': '1'}):
     assert digests(knobs) == ref, knobs
