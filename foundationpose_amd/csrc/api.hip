@@ -729,7 +729,7 @@ extern "C" int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const f
   return fp_score_predict_features_multi(ctx, net, &ob, 1, crop_ratio, normalize_xyz, d_poses, d_feats, stream);
 }
 
-int conv_halo_ksplit(const ConvArgs &a, int num_cu);      // conv_halo.hip
+int conv_ksplit(const ConvArgs &a, int num_cu);      // conv.hip
 
 // ---- building blocks ---------------------------------------------------------------------------------
 extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin, const void *d_w_packed, const float *d_bias,
@@ -764,7 +764,7 @@ extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int
   a.post_period = 1;
   a.tokens = 400;
   // launches of a few workgroups take the split-K form of the 3x3 stride-1 kernel, as inside the networks (1 .. 4 hypotheses)
-  a.ksplit = out_f32 ? 0 : conv_halo_ksplit(a, ctx->num_cu);
+  a.ksplit = out_f32 ? 0 : conv_ksplit(a, ctx->num_cu);
   if (a.ksplit > 1) {
     const size_t bytes = (size_t)a.ksplit * a.M * a.Cout * sizeof(float);
     FP_TRY(fp_arena_ensure(ctx, bytes + 4096));

@@ -55,8 +55,8 @@ __device__ __forceinline__ void glds16c(const f16 *g, f16 *l) {
 // One workgroup tile: 64 NT pixels x BM couts, 4 waves as 2 (cout halves) x 2 (pixel halves), each wave (BM/2) x 32 NT.
 // NT = 4 -> the 256-pixel main tiles, NT = 1 -> 64-pixel tail tiles (conv_igemm2_kernel).  The accumulation order of an
 // output element does not depend on NT.
-template <int BM, int KW, bool CIN8, int NT, bool RES>
-__device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__restrict__ zero_page, const int m0, const int c0, f16 *smem) {
+template <int BM, int KW, bool CIN8, int NT, bool RES, bool SPLIT = false>
+__device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__restrict__ zero_page, const int m0, const int c0, f16 *smem, const int ks = 0) {
   constexpr int TN = 64 * NT;                              // pixels per workgroup
   constexpr int XH = TN * C2_BK, WH = BM * C2_BK;          // halfs per stage
   constexpr int SLD = BM + 8;                              // halfs per staged output row
@@ -161,7 +161,8 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      const float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
+      float4 bv = *reinterpret_cast<const float4 *>(p.bias + c0 + wm * WM + i * 32 + rg * 8 + lh * 4);
+      if (SPLIT && ks != 0) bv = make_float4(0.f, 0.f, 0.f, 0.f);          // (split-K: the bias rides in share 0)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         acc[i][j][rg * 4 + 0] = bv.x;
@@ -171,20 +172,21 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
       }
     }
 
-  const int nk = p.Kpad / C2_BK;
+  // split-K (SPLIT): share ks of p.ksplit walks K-steps [kb, kb + nk) and leaves fp32 sums for splitk_finish_kernel (conv_halo.hip)
+  const int nk = SPLIT ? p.Kpad / C2_BK / p.ksplit : p.Kpad / C2_BK, kb = SPLIT ? ks * nk : 0;
   // 3-deep LDS-DMA ring: K-steps kt+1 and kt+2 stay in flight across the barrier (counted vmcnt + raw s_barrier;
   // a __syncthreads() would drain them).  Every wave issues exactly DMAW instructions per stage.
   constexpr int DMAW = NT + WQ;
   ISTAMP(const unsigned long long t_loop = __builtin_amdgcn_s_memtime();)
-  stage(0, 0);
-  if (nk > 1) stage(1, 1);
+  stage(kb, 0);
+  if (nk > 1) stage(kb + 1, 1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt % 3;
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DMAW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // stage kt landed for every wave; slot (kt+2)%3 was last read in step kt-1: free
     __builtin_amdgcn_sched_barrier(0);
-    if (kt + 2 < nk) stage(kt + 2, (kt + 2) % 3);
+    if (kt + 2 < nk) stage(kb + kt + 2, (kt + 2) % 3);
     const f16 *xs = smem + cur * (XH + WH), *ws = xs + XH;
     // two k-steps per stage, software-pipelined like the halo kernel: pixel-tile-major MFMA order, the pixel fragment of
     // step 1 is requested as soon as step 0's MFMAs on that register have been issued (counted lgkmcnt waits).  (Issuing
@@ -217,6 +219,20 @@ __device__ __forceinline__ void igemm2_tile(const ConvArgs &p, const f16 *__rest
   // it), no per-row output select when the whole tile lies on one side of split_m.  (Reading the residual as 8-byte
   // gathers in the accumulator layout behind the first DMA stages was measured: epilogue -6.8k cycles, K loop +16k.) ----
   ISTAMP(const unsigned long long t_epi = __builtin_amdgcn_s_memtime();)
+  if constexpr (SPLIT) {      // fp32 sums of this share -> p.splitk[ks][m][Cout], 16-byte stores in the accumulator layout
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int m = m0 + wn * (32 * NT) + j * 32 + lr;
+      if (m >= p.M) continue;
+      float *o = p.splitk + ((size_t)ks * p.M + m) * p.Cout + c0 + wm * WM + lh * 4;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          *reinterpret_cast<float4 *>(o + i * 32 + rg * 8) = make_float4(acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]);
+    }
+    return;
+  }
   if (p.out_mode == 0) {
     f16 *stage = smem;
     constexpr int CPR = BM / 8;           // 16-byte chunks per staged row
@@ -425,7 +441,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
   }
 }
 
+// Split-K form of the 3x3 stride-2 layer with the long K (256 -> 512 channels: 72 K-steps) at 1 .. 4 hypotheses, where the layer is
+// 28 .. 100 workgroups that each walk all of K behind one DMA round trip per step (38 us at one hypothesis): 64-pixel tiles,
+// p.ksplit workgroups per tile with an equal share of the K-steps each, fp32 sums to p.splitk, splitk_finish_kernel adds them in
+// share order (the scheme of conv3x3_halo_splitk_kernel: these batch sizes are the size class with its own last bits).
+template <int BM, int KW>
+__global__ __launch_bounds__(256, 2) void conv_igemm2_splitk_kernel(ConvArgs p, const f16 *__restrict__ zero_page) {
+  extern __shared__ __attribute__((aligned(16))) f16 smem[];
+  const int n_ct = p.Cout / BM;
+  const int ks = blockIdx.x % p.ksplit, t = blockIdx.x / p.ksplit;
+  const int m0 = (t / n_ct) * 64;
+  if (m0 >= p.M) return;
+  igemm2_tile<BM, KW, false, 1, false, true>(p, zero_page, m0, (t % n_ct) * BM, smem, ks);
+}
+
 void halo_split(int n_tiles, int slots, int *n_main, int *n_tail4);      // conv_halo.hip: main / quarter-tile split
+int launch_splitk_finish(const ConvArgs &a, hipStream_t s);              // conv_halo.hip
+int conv_halo_ksplit(const ConvArgs &a, int num_cu);                     // conv_halo.hip
+
+// Split factor of a launch (0: none): the 3x3 stride-1 layers by conv_halo_ksplit; the 3x3 stride-2 layer from 36 K-steps on when
+// its 64-pixel tiles fill at most a quarter of the workgroup slots (1 .. 4 hypotheses).  Decided by the caller that owns the scratch.
+int conv_ksplit(const ConvArgs &a, int num_cu) {
+  if (const int k = conv_halo_ksplit(a, num_cu)) return k;
+  const int nk = a.Kpad / C2_BK;
+  if (a.KH == 3 && a.KW == 3 && a.stride == 2 && a.out_mode == 0 && a.Cin % 32 == 0 && a.Cout % 128 == 0 && a.M < S2_MIN_PIXELS && nk >= 36 && nk % 4 == 0 &&
+      ((a.M + 63) / 64) * (a.Cout / 128) * 4 <= 2 * num_cu)
+    return 4;
+  return 0;
+}
 
 template <int BM>
 constexpr int igemm2_lds_bytes() {
@@ -440,6 +483,7 @@ static void igemm2_lds_both(std::vector<KernelLds> &v) {
 }
 
 void conv_kernel_lds(std::vector<KernelLds> &v) {       // every instantiation launch_conv can reach
+  v.push_back({(const void *)conv_igemm2_splitk_kernel<128, 3>, igemm2_lds_bytes<128>()});
   igemm2_lds_both<128, 7, true>(v), igemm2_lds_both<64, 7, true>(v);
   igemm2_lds_both<128, 3, false>(v), igemm2_lds_both<64, 3, false>(v);
   igemm2_lds_both<128, 1, false>(v), igemm2_lds_both<64, 1, false>(v);
@@ -487,6 +531,13 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
     if (band != 0 && (a.Cin == 128 || band == 2) && (long long)a.M > (long long)ctx->num_cu * 512 && s1b_supported(a)) return launch_conv_s1b(ctx, a, s);
   }
   if (halo) return launch_conv_halo(ctx, a, s);
+  if (a.splitk && a.ksplit > 1) {        // (conv_ksplit: the 3x3 stride-2 layer with the long K at 1 .. 4 hypotheses)
+    FP_REQUIRE(a.KW == 3 && a.stride == 2 && a.Cout % 128 == 0 && (a.Kpad / C2_BK) % a.ksplit == 0 && a.out_mode == 0, "conv split-K: unsupported layer");
+    const int n_t = ((a.M + 63) / 64) * (a.Cout / 128);
+    hipLaunchKernelGGL((conv_igemm2_splitk_kernel<128, 3>), dim3(n_t * a.ksplit), dim3(256), igemm2_lds_bytes<128>(), s, a, (const f16 *)ctx->zero_page);
+    FP_CHECK_HIP(hipGetLastError());
+    return launch_splitk_finish(a, s);
+  }
   if (stem_supported(a)) return launch_stem(ctx, a, s);
   if (a.wpk && a.M >= S2_MIN_PIXELS && s2_supported(a)) return launch_conv_s2(ctx, a, s);
   const bool bm128 = (a.Cout % 128 == 0);

@@ -576,14 +576,19 @@ static int launch_halo_dma_flags(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) 
   return a.res ? launch_halo_dma<W, true, false>(ctx, a, s) : launch_halo_dma<W, false, false>(ctx, a, s);
 }
 
+int launch_splitk_finish(const ConvArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((a.M * (a.Cout / 4) + 255) / 256), dim3(256), 0, s, a);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
 template <int W>
 static int launch_halo_splitk(const ConvArgs &a, hipStream_t s) {
   using C = HaloCfgD<W, 128>;
   const int n_q = ((a.M + 127) / 128) * (a.Cout / HL_BM);
   hipLaunchKernelGGL((conv3x3_halo_splitk_kernel<W>), dim3(n_q * a.ksplit), dim3(512), C::LDS_BYTES, s, a);
-  hipLaunchKernelGGL(splitk_finish_kernel, dim3((a.M * (a.Cout / 4) + 255) / 256), dim3(256), 0, s, a);
   FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
+  return launch_splitk_finish(a, s);
 }
 
 // Split factor for a launch of this shape: 0 unless the quarter tiles fill at most a quarter of the CUs (1 .. 4 hypotheses);

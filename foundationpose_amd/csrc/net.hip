@@ -295,7 +295,7 @@ extern "C" int fp_net_rot_dim(const fp_net *net) { return (net && net->kind == F
 // ---------------------------------------------------------------------------------------------
 // forward schedules
 // ---------------------------------------------------------------------------------------------
-int conv_halo_ksplit(const ConvArgs &a, int num_cu);      // conv_halo.hip
+int conv_ksplit(const ConvArgs &a, int num_cu);      // conv.hip
 
 namespace {
 
@@ -343,7 +343,7 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
   a.post_period = c.post_period;
   a.tokens = c.tokens;
   if (splitk_scratch) {
-    a.ksplit = conv_halo_ksplit(a, ctx->num_cu);
+    a.ksplit = conv_ksplit(a, ctx->num_cu);
     a.splitk = a.ksplit > 1 ? splitk_scratch : nullptr;
   }
   return launch_conv(ctx, a, s);

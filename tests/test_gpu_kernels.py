@@ -390,6 +390,8 @@ def _pack_conv_weight(w, cin_pad):
   (1, 20, 20, 512, 512, 3, 1, True, True),          # one hypothesis: 16 quarter tiles -> split-K, 4 shares of 4 chunks + finishing pass
   (1, 40, 40, 256, 256, 3, 1, False, True),         # split-K, 4 shares of 2 chunks
   (2, 40, 40, 128, 128, 3, 1, True, False),         # split-K, 2 shares of 2 chunks, no ReLU
+  (1, 40, 40, 256, 512, 3, 2, False, True),         # stride 2, 72 K-steps at one hypothesis: split-K of the implicit GEMM (4 shares of 18 steps), last 64-pixel tile partial
+  (4, 40, 40, 256, 512, 3, 2, False, False),        # the same at the largest batch that takes it (1600 pixels), no ReLU
   (1, 1, 1000, 512, 1024, 1, 1, False, False),     # a Linear layer (1x1, M=1000 tokens: ragged last tile)
   (1, 1, 130, 512, 64, 1, 1, False, False),
 ])
