@@ -154,10 +154,11 @@ def bilateral_filter_depth(depth, radius=2, zfar=100, sigmaD=2, sigmaR=100000, d
   return out
 
 
-def depth_prefilter(depth, K, radius=2, depth_diff_thres=0.001, ratio_thres=0.8, zfar=100, sigmaD=2, sigmaR=100000, zfar_xyz=np.inf):
+def depth_prefilter(depth, K, radius=2, depth_diff_thres=0.001, ratio_thres=0.8, zfar=100, sigmaD=2, sigmaR=100000, zfar_xyz=np.inf, rgb_u8=None):
   """The depth prelude of a tracking frame (src/estimater.py:256-260) in one launch (a build extension; not in the reference):
   bilateral_filter_depth(erode_depth(depth, radius), radius) and depth2xyzmap_batch of the result with the float32 camera matrix.
-  Returns (depth (H,W), xyz_map (H,W,3)) on the device, bit-identical to the three calls chained."""
+  Returns (depth (H,W), xyz_map (H,W,3)) on the device, bit-identical to the three calls chained; with `rgb_u8` (H,W,3) uint8 on the
+  device also its float copy (rgb_u8.to(torch.float)) as a third value, from the same launch."""
   d = torch.as_tensor(depth, dtype=torch.float, device='cuda').contiguous()
   ctx = _lib.Context.get(d.device)
   H, W = d.shape
@@ -165,9 +166,14 @@ def depth_prefilter(depth, K, radius=2, depth_diff_thres=0.001, ratio_thres=0.8,
   xyz = torch.empty((H, W, 3), dtype=torch.float, device=d.device)
   Kd, Kp = k_ptr(np.asarray(K.detach().cpu().numpy() if torch.is_tensor(K) else K, dtype=np.float32))
   zf = float(zfar_xyz) if np.isfinite(zfar_xyz) else 3.0e38
+  rgb_f = None
+  if rgb_u8 is not None:
+    if not (torch.is_tensor(rgb_u8) and rgb_u8.is_cuda and rgb_u8.dtype == torch.uint8 and tuple(rgb_u8.shape) == (H, W, 3) and rgb_u8.is_contiguous()):
+      raise ValueError('depth_prefilter: rgb_u8 must be a contiguous (H,W,3) uint8 tensor on the device')
+    rgb_f = torch.empty((H, W, 3), dtype=torch.float, device=d.device)
   check(lib().fp_depth_prefilter(ctx.handle, ptr(d), H, W, int(radius), float(depth_diff_thres), float(ratio_thres), float(zfar), float(zfar),
-                                 float(sigmaD), float(sigmaR), Kp, zf, ptr(out), ptr(xyz), stream_ptr(d.device)))
-  return out, xyz
+                                 float(sigmaD), float(sigmaR), Kp, zf, ptr(out), ptr(xyz), ptr(rgb_u8), ptr(rgb_f), stream_ptr(d.device)))
+  return (out, xyz) if rgb_u8 is None else (out, xyz, rgb_f)
 
 
 def depth2xyzmap(depth, K, uvs=None):

@@ -60,7 +60,7 @@ _PROTOS = {
   'fp_bilateral_filter_depth': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
   'fp_depth2xyzmap': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
   'fp_depth_prefilter': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p, c_float,
-                                 c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
   'fp_depth2xyzmap_f64': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_mask_depth_stats': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
   'fp_net_create': (c_int, [c_void_p, c_int, POINTER(FpTensor), c_int, c_int, POINTER(c_void_p)]),

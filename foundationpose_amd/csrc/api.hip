@@ -436,13 +436,14 @@ extern "C" int fp_depth2xyzmap(fp_ctx *ctx, const float *d_depth, int H, int W, 
 
 extern "C" int fp_depth_prefilter(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
                                   float zfar_erode, float zfar_bilateral, float sigmaD, float sigmaR, const double *K, float zfar_xyz,
-                                  float *d_depth_out, float *d_xyz, void *stream) {
+                                  float *d_depth_out, float *d_xyz, const uint8_t *d_rgb_u8, float *d_rgb_f32, void *stream) {
   FP_REQUIRE(ctx && d_depth && d_depth_out && d_xyz && K && H > 0 && W > 0, "fp_depth_prefilter: bad argument");
+  FP_REQUIRE((d_rgb_u8 == nullptr) == (d_rgb_f32 == nullptr), "fp_depth_prefilter: d_rgb_u8 and d_rgb_f32 go together");
   FP_REQUIRE(radius == 2, "fp_depth_prefilter: radius %d (the fused prelude is built for the radius 2 of src/estimater.py:256-257; "
                           "other radii: fp_erode_depth, fp_bilateral_filter_depth, fp_depth2xyzmap)", radius);
   FP_REQUIRE(d_depth != d_depth_out, "fp_depth_prefilter: in-place filtering is not possible (neighbouring workgroups read the input)");
   return launch_depth_prefilter(d_depth, H, W, depth_diff_thres, ratio_thres, zfar_erode, zfar_bilateral, sigmaD, sigmaR, K, zfar_xyz, d_depth_out,
-                                d_xyz, (hipStream_t)stream);
+                                d_xyz, d_rgb_u8, d_rgb_f32, (hipStream_t)stream);
 }
 
 extern "C" int fp_depth2xyzmap_f64(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float *d_xyz, void *stream) {

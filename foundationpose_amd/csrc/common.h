@@ -374,6 +374,6 @@ int launch_erode(const float *d, int H, int W, int radius, float diff_thres, flo
 int launch_bilateral(const float *d, int H, int W, int radius, float zfar, float sigmaD, float sigmaR, float *out, hipStream_t s);
 int launch_depth2xyz(const float *d, int H, int W, const double *K, float zfar, float *xyz, hipStream_t s);
 int launch_depth_prefilter(const float *d, int H, int W, float diff_thres, float ratio_thres, float zfar_e, float zfar_b, float sigmaD,
-                           float sigmaR, const double *K, float zfar_x, float *out, float *xyz, hipStream_t s);
+                           float sigmaR, const double *K, float zfar_x, float *out, float *xyz, const unsigned char *rgb_u8, float *rgb_f, hipStream_t s);
 int launch_depth2xyz_f64(const float *d, int H, int W, const double *K, float *xyz, hipStream_t s);
 int launch_mask_depth_stats(const float *d, const unsigned char *mask, int H, int W, float min_depth, int *out6, float *median, hipStream_t s);

@@ -205,10 +205,13 @@ class FoundationPose:
     perturbations of it + scoring.  Returns (new pose (4,4), poses, scores, best_id, new pose @ get_tf_to_centered_mesh()) -
     device tensors."""
     from .tracking import tracking_hypotheses
-    rgb = rgb.to(torch.float)
     # erode_depth -> bilateral_filter_depth -> depth2xyzmap_batch (src/estimater.py:256-260; the reference back-projects with the
-    # float32 camera matrix here), one launch
-    depth, xyz_map = U.depth_prefilter(depth, K, radius=2)
+    # float32 camera matrix here), one launch; a uint8 frame's colours become float in the same launch
+    if rgb.dtype == torch.uint8 and rgb.is_contiguous() and tuple(rgb.shape) == tuple(depth.shape) + (3,):
+      depth, xyz_map, rgb = U.depth_prefilter(depth, K, radius=2, rgb_u8=rgb)
+    else:
+      rgb = rgb.to(torch.float)
+      depth, xyz_map = U.depth_prefilter(depth, K, radius=2)
     shared = dict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K, glctx=self.glctx, mesh_diameter=self.diameter)
     if n_hyp == 1:
       pose, _ = self.refiner.predict(ob_in_cams=pose_in.reshape(-1, 4, 4), normal_map=None, xyz_map=xyz_map, iteration=iteration,

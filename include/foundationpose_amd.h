@@ -109,10 +109,11 @@ int fp_bilateral_filter_depth(fp_ctx *ctx, const float *d_depth, int H, int W, i
 int fp_depth2xyzmap(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float zfar, float *d_xyz, void *stream);
 /* The depth prelude of a tracking frame (src/estimater.py:256-260: erode_depth -> bilateral_filter_depth -> depth2xyzmap_batch) in
    one launch; `radius` must be 2 (both filters, as the reference calls them).  d_depth_out (H,W) and d_xyz (H,W,3) are bit-identical
-   to the three calls above chained; d_depth_out must not alias d_depth. */
+   to the three calls above chained; d_depth_out must not alias d_depth.  Optionally the frame's colours ride along: d_rgb_u8 (H,W,3)
+   uint8 -> d_rgb_f32 (H,W,3) float (what fp_crop_observed and the fused passes read); both null: not done. */
 int fp_depth_prefilter(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
                        float zfar_erode, float zfar_bilateral, float sigmaD, float sigmaR, const double *K, float zfar_xyz,
-                       float *d_depth_out, float *d_xyz, void *stream);
+                       float *d_depth_out, float *d_xyz, const uint8_t *d_rgb_u8, float *d_rgb_f32, void *stream);
 /* depth2xyzmap of the registration path (src/Utils.py:399-417): float64 arithmetic, one rounding to float32, depth < 0.001 -> 0. */
 int fp_depth2xyzmap_f64(fp_ctx *ctx, const float *d_depth, int H, int W, const double *K, float *d_xyz, void *stream);
 /* The reductions behind FoundationPose.guess_translation and the "valid too small" test of register()

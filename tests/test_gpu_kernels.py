@@ -314,6 +314,9 @@ def test_depth_prefilter_equals_the_three_kernels_chained(sc, fp, hw):
   assert fused_d.shape == (H, W) and fused_x.shape == (H, W, 3)
   assert torch.equal(fused_d, chain_d), int((fused_d != chain_d).sum())
   assert torch.equal(fused_x, chain_x)
+  rgb = torch.from_numpy(rs.randint(0, 256, (H, W, 3)).astype(np.uint8)).cuda()
+  d3, x3, rgb_f = U.depth_prefilter(dt, sc['K'], radius=2, rgb_u8=rgb)             # the frame's colours in the same launch
+  assert torch.equal(d3, chain_d) and torch.equal(x3, chain_x) and torch.equal(rgb_f, rgb.to(torch.float))
   if H * W > 1000:
     assert float((fused_d > 0).float().mean()) > 0.2 and float((fused_d == 0).float().mean()) > 0.02      # (both outcomes of the erosion occur)
   with pytest.raises(RuntimeError, match='radius'):
