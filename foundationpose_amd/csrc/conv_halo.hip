@@ -428,7 +428,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, in
 
 // Split-K form for launches of a few workgroups (1 .. 4 hypotheses): every tile is a 128-pixel quarter tile, p.ksplit workgroups
 // per tile each take an equal share of the input-channel chunks.  At one hypothesis a 512-channel layer is 16 workgroups that
-// each walk 48 weight groups behind one DMA round trip apiece (40 us); four shares of 12 groups + the finishing pass take a third.
+// each walk 48 weight groups behind one DMA round trip apiece (40 us); four shares of 12 groups + the finishing pass take a third,
+// eight shares of 6 (1 and 2 hypotheses: the grid still fits the chip) another 2 % of a one-hypothesis step.
 template <int W>
 __global__ __launch_bounds__(512, 1) void conv3x3_halo_splitk_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) f16 lds[];
@@ -592,12 +593,14 @@ static int launch_halo_splitk(const ConvArgs &a, hipStream_t s) {
 }
 
 // Split factor for a launch of this shape: 0 unless the quarter tiles fill at most a quarter of the CUs (1 .. 4 hypotheses);
-// then as many shares as keep >= 2 chunks per share and the grid within the chip.  Decided by the caller that owns the scratch.
+// then as many shares (at most 8; FP_KSPLIT_MAX) as keep >= 2 chunks per share and the grid within the chip.  Decided by the caller
+// that owns the scratch (its size: shares x M x Cout floats <= 4 x hypotheses x 1600 x 256 for every layer of the networks).
 int conv_halo_ksplit(const ConvArgs &a, int num_cu) {
   if (!conv_halo_supported(a)) return 0;
   const int n_q = ((a.M + 127) / 128) * (a.Cout / HL_BM), nchunk = a.Cin / HL_CK;
   if (n_q * 4 > num_cu) return 0;
-  int k = 4;
+  static const int k_max = getenv("FP_KSPLIT_MAX") ? atoi(getenv("FP_KSPLIT_MAX")) : 8;
+  int k = k_max;
   while (k > 1 && (nchunk % k != 0 || nchunk / k < 2 || n_q * k > num_cu)) k >>= 1;
   return k > 1 ? k : 0;
 }

@@ -390,7 +390,7 @@ def _pack_conv_weight(w, cin_pad):
   (9, 40, 40, 256, 512, 3, 2, False, True),         # band-in-LDS stride-2 kernel (conv_s2.hip): 8-row tiles straddle images, last tile partial
   (9, 40, 40, 64, 128, 3, 2, False, False),         # the same with 128-cout blocks, no ReLU
   (2, 160, 160, 6, 64, 7, 2, False, True),
-  (1, 20, 20, 512, 512, 3, 1, True, True),          # one hypothesis: 16 quarter tiles -> split-K, 4 shares of 4 chunks + finishing pass
+  (1, 20, 20, 512, 512, 3, 1, True, True),          # one hypothesis: 16 quarter tiles -> split-K, 8 shares of 2 chunks + finishing pass
   (1, 40, 40, 256, 256, 3, 1, False, True),         # split-K, 4 shares of 2 chunks
   (2, 40, 40, 128, 128, 3, 1, True, False),         # split-K, 2 shares of 2 chunks, no ReLU
   (1, 40, 40, 256, 512, 3, 2, False, True),         # stride 2, 72 K-steps at one hypothesis: split-K of the implicit GEMM (4 shares of 18 steps), last 64-pixel tile partial

@@ -471,18 +471,6 @@ def test_to_device_moves_the_predictors(nets_gpu):
   assert est.some_tensor.is_cuda and est.mesh_tensors['pos'].is_cuda
 
 
-def test_kernel_variants_reproduce_the_goldens():
-  """Kernel variants that an environment knob selects (read once per process, so each runs in ONE child process): the 128 -> 128
-  convolutions on the general 3x3 kernel instead of the band form (FP_C128_BAND=0), the one-stream trunk and heads (FP_TRUNK_STREAMS=1, FP_HEADS_SERIAL=1).  Each
-  must reproduce the reference modules' golden outputs under the same rules as the default build."""
-  import os, subprocess, sys
-  script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'check_kernel_variant.py')
-  for knobs in ({'FP_C128_BAND': '0'}, {'FP_TRUNK_STREAMS': '1', 'FP_HEADS_SERIAL': '1'}):
-    r = subprocess.run([sys.executable, script], env=dict(os.environ, **knobs), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, f'{knobs}: {r.stdout[-1500:]}\n{r.stderr[-1500:]}'
-    assert 'variant ok' in r.stdout
-
-
 def test_schedules_and_kernel_forms_are_bit_identical():
   """Schedules and kernel forms that claim bit-identical results (one process each: the knobs are read once): the two sides of encodeA as
   one chain instead of two (FP_ONE_CHAIN=1), the trunk as one batch instead of two halves on two streams (FP_TRUNK_STREAMS=1), both heads
