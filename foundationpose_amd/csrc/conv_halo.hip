@@ -593,13 +593,17 @@ static int launch_halo_splitk(const ConvArgs &a, hipStream_t s) {
 }
 
 // Split factor for a launch of this shape: 0 unless the quarter tiles fill at most a quarter of the CUs (1 .. 4 hypotheses);
-// then as many shares (at most 8; FP_KSPLIT_MAX) as keep >= 2 chunks per share and the grid within the chip.  Decided by the caller
+// then, from 8 chunks (256 channels) on, as many shares (at most 8; FP_KSPLIT_MAX) as keep >= 2 chunks per share and the grid within the chip.  Decided by the caller
 // that owns the scratch (its size: shares x M x Cout floats <= 4 x hypotheses x 1600 x 256 for every layer of the networks).
 int conv_halo_ksplit(const ConvArgs &a, int num_cu) {
   if (!conv_halo_supported(a)) return 0;
   const int n_q = ((a.M + 127) / 128) * (a.Cout / HL_BM), nchunk = a.Cin / HL_CK;
   if (n_q * 4 > num_cu) return 0;
   static const int k_max = getenv("FP_KSPLIT_MAX") ? atoi(getenv("FP_KSPLIT_MAX")) : 8;
+  // from 256 input channels on: with the four chunks of a 128-channel layer two shares + the finishing launch take longer than the one
+  // launch (one-hypothesis step 2.17 -> 2.12 ms, four hypotheses 2.74 -> 2.56 without them; FP_KSPLIT_MIN_CHUNKS=0: split those too)
+  static const int min_chunks = getenv("FP_KSPLIT_MIN_CHUNKS") ? atoi(getenv("FP_KSPLIT_MIN_CHUNKS")) : 8;
+  if (nchunk < min_chunks) return 0;
   int k = k_max;
   while (k > 1 && (nchunk % k != 0 || nchunk / k < 2 || n_q * k > num_cu)) k >>= 1;
   return k > 1 ? k : 0;

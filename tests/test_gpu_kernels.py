@@ -392,7 +392,8 @@ def _pack_conv_weight(w, cin_pad):
   (2, 160, 160, 6, 64, 7, 2, False, True),
   (1, 20, 20, 512, 512, 3, 1, True, True),          # one hypothesis: 16 quarter tiles -> split-K, 8 shares of 2 chunks + finishing pass
   (1, 40, 40, 256, 256, 3, 1, False, True),         # split-K, 4 shares of 2 chunks
-  (2, 40, 40, 128, 128, 3, 1, True, False),         # split-K, 2 shares of 2 chunks, no ReLU
+  (2, 40, 40, 128, 128, 3, 1, True, False),         # 26 quarter tiles of a 128-channel layer: too few chunks to split, one launch of 128-pixel tiles, no ReLU
+  (2, 40, 40, 256, 256, 3, 1, True, False),         # split-K, 4 shares of 2 chunks, residual, no ReLU
   (1, 40, 40, 256, 512, 3, 2, False, True),         # stride 2, 72 K-steps at one hypothesis: split-K of the implicit GEMM (4 shares of 18 steps), last 64-pixel tile partial
   (4, 40, 40, 256, 512, 3, 2, False, False),        # the same at the largest batch that takes it (1600 pixels), no ReLU
   (1, 1, 1000, 512, 1024, 1, 1, False, False),     # a Linear layer (1x1, M=1000 tokens: ragged last tile)
