@@ -727,10 +727,11 @@ RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu) {
   if (rows_max > Ho) rows_max = Ho;
   if (rows_max < 1) rows_max = 1;
   int S = (Ho + rows_max - 1) / rows_max;
-  // 40-row strips of a 160-row crop; thinner ones while the launch is still under one workgroup per CU (a workgroup's resolve
-  // pass shrinks with its strip)
+  // 27-row strips of a 160-row crop; thinner ones while the launch is under ~0.8 workgroups per CU (a workgroup's resolve pass shrinks
+  // with its strip; twice the strips are then still under two rounds)
   while (S < 4 && Ho / (S * 2) >= 8) S *= 2;
-  while ((size_t)N * S * 2 <= (size_t)num_cu && S < 16 && Ho / (S * 2) >= 8) S *= 2;
+  // (measured, 160x160 crops of the 16k-face mesh, strips 6 -> 12: 24 hypotheses 58 -> 49 us, 32: 72 -> 62, 40: 72 -> 78, 63: 92 -> 100)
+  while ((size_t)N * S * 5 <= (size_t)num_cu * 4 && S < 16 && Ho / (S * 2) >= 8) S *= 2;
   p.strip_rows = (Ho + S - 1) / S;
   p.S = (Ho + p.strip_rows - 1) / p.strip_rows;
   p.lds_bytes = (size_t)p.strip_rows * Wo * 8 + ((((size_t)p.strip_rows * Wo * 2) + 15) & ~(size_t)15) + p.a_lds;
