@@ -14,6 +14,9 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, res)
   'stem_7x7': (504, 160, 160, 8, 64, 7, 2, False),
   'linear_512_1024': (1, 1, 100800, 512, 1024, 1, 1, False),
   'linear_512_512': (1, 1, 100800, 512, 512, 1, 1, True),
+  'trk_128': (1, 40, 40, 128, 128, 3, 1, True),        # tracking, one hypothesis: a side's encodeA layer (13 tiles of 128 px)
+  'trk_256': (1, 40, 40, 256, 256, 3, 1, True),        # ... encodeAB at 40x40 (split-K)
+  'trk_512': (1, 20, 20, 512, 512, 3, 1, True),        # ... encodeAB at 20x20 (split-K)
 }
 
 def main():
