@@ -12,6 +12,8 @@ dev = torch.device('cuda', 0)
 est, objects = bench.build_job(dev, n_objects=1, rank=0)
 est.refiner.ctx.reserve(64)
 n = int(os.environ.get('FRAMES', '300'))
+n_hyp = int(os.environ.get('HYP', '64'))
+est.refiner.ctx.reserve(max(64, n_hyp))
 K = S.YCB_K
 poses = torch.as_tensor(trajectory(n), device=dev)
 rgbs, depths = [], []
@@ -25,11 +27,11 @@ def run(mode, graph):
   out = []
   for f in range(n):
     est.pose_last = starts[f]
-    out.append(est.track_one(rgbs[f], depths[f], K, iteration=2) if mode == 'one' else est.track_multi(rgbs[f], depths[f], K, iteration=2, n_hypotheses=64))
+    out.append(est.track_one(rgbs[f], depths[f], K, iteration=2) if mode == 'one' else est.track_multi(rgbs[f], depths[f], K, iteration=2, n_hypotheses=n_hyp))
   return np.stack(out)
 for mode in ('one', 'multi'):
   a, b, c = run(mode, False), run(mode, False), run(mode, True)
   bad_e = int((a != b).any(axis=(1, 2)).sum()); bad_g = int((a != c).any(axis=(1, 2)).sum())
-  print(f'{mode}: {n} frames, eager vs eager differing frames {bad_e}, eager vs graph {bad_g}, finite {bool(np.isfinite(a).all())}')
+  print(f'{mode} ({1 if mode == "one" else n_hyp} hypotheses): {n} frames, eager vs eager differing frames {bad_e}, eager vs graph {bad_g}, finite {bool(np.isfinite(a).all())}')
   assert bad_e == 0 and bad_g == 0
 print('soak ok')
