@@ -101,6 +101,7 @@ def nvdiffrast_render(K=None, H=None, W=None, ob_in_cams=None, glctx=None, conte
   else:
     # light_dir / light_pos / light_color / projection_mat (src/Utils.py:159-161,200-211) travel in fp_render_opts
     o = _lib.FpRenderOpts()
+    o.struct_size = ctypes.sizeof(o)
     o.use_light, o.w_ambient, o.w_diffuse = (1 if use_light else 0), float(w_ambient), float(w_diffuse)
     if default_light:
       o.light_mode = 0

@@ -29,7 +29,7 @@ class FpRefineCfg(Structure):
 
 class FpRenderOpts(Structure):
   """fp_render_opts (include/foundationpose_amd.h): the non-default arguments of nvdiffrast_render."""
-  _fields_ = [('use_light', c_int), ('w_ambient', c_float), ('w_diffuse', c_float), ('light_mode', c_int), ('light_vec', c_float * 3),
+  _fields_ = [('struct_size', ctypes.c_size_t), ('use_light', c_int), ('w_ambient', c_float), ('w_diffuse', c_float), ('light_mode', c_int), ('light_vec', c_float * 3),
               ('has_light_color', c_int), ('light_color', c_float * 3), ('has_projection', c_int), ('projection', c_double * 16), ('d_rast', c_void_p)]
 
 

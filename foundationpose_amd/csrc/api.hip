@@ -343,10 +343,19 @@ extern "C" int fp_render(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses,
 }
 
 extern "C" int fp_render_ex(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
-                            const float *d_bbox2d, int out_h, int out_w, const fp_render_opts *opts, float *d_color, float *d_depth,
+                            const float *d_bbox2d, int out_h, int out_w, const fp_render_opts *opts_in, float *d_color, float *d_depth,
                             float *d_normal, float *d_xyz, void *stream) {
   FP_REQUIRE(ctx, "fp_render_ex: null ctx");
-  if (!opts) return fp_render(ctx, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w, 0, 0.8f, 0.5f, d_color, d_depth, d_normal, d_xyz, stream);
+  if (!opts_in) return fp_render(ctx, mesh, d_poses, N, K, H, W, d_bbox2d, out_h, out_w, 0, 0.8f, 0.5f, d_color, d_depth, d_normal, d_xyz, stream);
+  // versioned by size: a caller built against the header before `d_rast` passes a shorter struct - never read past what it holds
+  fp_render_opts o;
+  memset(&o, 0, sizeof(o));
+  {
+    const size_t sz = opts_in->struct_size, sz_r4 = offsetof(fp_render_opts, d_rast);
+    FP_REQUIRE(sz == sizeof(fp_render_opts) || sz == sz_r4, "fp_render_ex: fp_render_opts.struct_size = %zu (this library knows %zu and %zu)", sz, sz_r4, sizeof(fp_render_opts));
+    memcpy(&o, opts_in, sz);
+  }
+  const fp_render_opts *opts = &o;
   FP_REQUIRE(opts->light_mode >= 0 && opts->light_mode <= 2, "fp_render_ex: light_mode %d unknown", opts->light_mode);
   static const double unit_k[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   FP_REQUIRE(K || opts->has_projection, "fp_render_ex: neither K nor a projection matrix");
@@ -368,7 +377,7 @@ extern "C" int fp_render_ex(fp_ctx *ctx, const fp_mesh *mesh, const float *d_pos
   return render_with_arena_scratch(ctx, a, (hipStream_t)stream);
 }
 
-// scratch: render_plan(N, ...).total bytes for the vertex pre-pass and the strip face lists (nullptr: taken from the arena here)
+// scratch: render_scratch_bytes(N, ...) bytes for the vertex pre-pass and the strip face lists (nullptr: taken from the arena here)
 static int render_net_impl(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, const double *K, int H, int W,
                            const float *d_bbox2d, int out_h, int out_w, double mesh_diameter, int normalize_xyz, float invalid_thres,
                            void *d_net_out, void *scratch, size_t scratch_bytes, void *stream) {

@@ -65,7 +65,7 @@ template <bool V> struct FaBool { static constexpr bool value = V; };
 // [0] entry, [31] exit; of the workgroup's SECOND item (its first when it has only one): [1] item start, then per key block
 // {barrier passed, S done, softmax done, PV done}, [2] stores issued
 __device__ unsigned long long g_attn_stamps[1024 * 7 * 32];
-extern "C" int fp_dbg_attn_stamps(unsigned long long *host) {
+extern "C" __attribute__((visibility("default"))) int fp_dbg_attn_stamps(unsigned long long *host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(g_attn_stamps)) == hipSuccess ? 0 : -1;
 }
 #define ASTAMP(i) do { if (blockIdx.x < 1024 && stamp_on) st[(i)] = __builtin_amdgcn_s_memtime(); } while (0)

@@ -144,6 +144,11 @@ struct StreamFanout {
     if (rc != FP_OK) fp_set_error("stream fork/join failed");
     return rc;
   }
+  // every way out of a scope that forked - an early FP_REQUIRE / FP_TRY return included - joins the side streams before the caller
+  // resets the arena they may still be writing (join() is idempotent: a joined fan-out has no used stream left)
+  ~StreamFanout() { (void)join(); }
+  StreamFanout(const StreamFanout &) = delete;
+  StreamFanout &operator=(const StreamFanout &) = delete;
 };
 
 

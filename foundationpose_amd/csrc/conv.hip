@@ -32,7 +32,7 @@
 #ifdef HALO_STAMP
 // diagnostic build only (make -B EXTRA=-DHALO_STAMP): per-wave cycle counts of prologue / K loop / epilogue
 __device__ unsigned long long g_igemm_stamps[4096 * 4 * 4];
-extern "C" int fp_dbg_igemm_stamps(unsigned long long *host) {
+extern "C" __attribute__((visibility("default"))) int fp_dbg_igemm_stamps(unsigned long long *host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm_stamps), sizeof(g_igemm_stamps)) == hipSuccess ? 0 : -1;
 }
 #define ISTAMP(x) x

@@ -27,7 +27,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // 16-byte reg
 #ifdef HALO_STAMP
 // diagnostic build only (make STAMP=1): per-wave cycle sums of [wait + barrier] and [group body], see scripts/halo_stamps.py
 __device__ unsigned long long g_halo_stamps[4096 * 8 * 8];
-extern "C" int fp_dbg_halo_stamps(unsigned long long *host, int clear) {
+extern "C" __attribute__((visibility("default"))) int fp_dbg_halo_stamps(unsigned long long *host, int clear) {
   if (host) (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_halo_stamps), sizeof(g_halo_stamps));
   if (clear) {
     static unsigned long long z[4096 * 8 * 8];

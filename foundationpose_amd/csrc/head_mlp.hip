@@ -282,7 +282,7 @@ __global__ __launch_bounds__(HM_THREADS, 1) void head_mlp_kernel(HeadMlpArgs p) 
 #ifdef HM_STAMP
 // diagnostic build only (make -B EXTRA=-DHM_STAMP; scripts/hm_stamps.py): s_memtime per wave at the phase boundaries of head_mlp128_kernel
 __device__ unsigned long long g_hm_stamps[1024 * 8 * 8];
-extern "C" int fp_dbg_hm_stamps(unsigned long long *host) {
+extern "C" __attribute__((visibility("default"))) int fp_dbg_hm_stamps(unsigned long long *host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_hm_stamps), sizeof(g_hm_stamps)) == hipSuccess ? 0 : -1;
 }
 #define HSTAMP(i) do { if (blockIdx.x < 1024 && c.lane == 0) g_hm_stamps[((size_t)blockIdx.x * 8 + c.wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)

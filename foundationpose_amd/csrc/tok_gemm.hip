@@ -48,7 +48,7 @@ typedef unsigned int tg_u32x4 __attribute__((ext_vector_type(4)));
 #ifdef HALO_STAMP
 // diagnostic build only (make -B EXTRA=-DHALO_STAMP): s_memtime per wave at entry / tile resident / K loop done / exit
 __device__ unsigned long long g_tok_stamps[2048 * 4 * 4];
-extern "C" int fp_dbg_tok_stamps(unsigned long long *host) {
+extern "C" __attribute__((visibility("default"))) int fp_dbg_tok_stamps(unsigned long long *host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tok_stamps), sizeof(g_tok_stamps)) == hipSuccess ? 0 : -1;
 }
 #define TSTAMP(i) do { if (blockIdx.x < 2048 && lane == 0) g_tok_stamps[((size_t)blockIdx.x * 4 + wave) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)

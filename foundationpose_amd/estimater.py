@@ -79,6 +79,9 @@ class FoundationPose:
     self.mesh_tensors = U.make_mesh_tensors(centred)
     sym = torch.eye(4)[None] if symmetry_tfs is None else torch.as_tensor(symmetry_tfs)
     self.symmetry_tfs = sym.to(device='cuda', dtype=torch.float)
+    # captured tracking graphs hold the addresses of the previous object's mesh and centring matrix: none survives a new object
+    self._graphs = {}
+    self._tf_centered_key = None
     logging.info("reset done")
 
   def get_tf_to_centered_mesh(self):

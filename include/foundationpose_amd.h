@@ -18,11 +18,15 @@
 #ifndef FOUNDATIONPOSE_AMD_H
 #define FOUNDATIONPOSE_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* The library is built with -fvisibility=hidden: the declarations of this header are its ONLY dynamic symbols. */
+#pragma GCC visibility push(default)
 
 #define FP_OK 0
 #define FP_EINVAL (-1)   /* bad argument / shape */
@@ -69,6 +73,8 @@ int fp_render(fp_ctx *ctx, const fp_mesh *mesh, const float *d_poses, int N, con
 /* The same with the non-default arguments of nvdiffrast_render: light_dir / light_pos / light_color (src/Utils.py:200-211)
  * and projection_mat (src/Utils.py:159-161).  opts == NULL is fp_render with use_light = 0. */
 typedef struct fp_render_opts {
+  size_t struct_size;      /* = sizeof(fp_render_opts) of the header the CALLER was built against: fields beyond it are read as 0 / NULL,
+                            * a size the library does not know is refused (FP_EINVAL) */
   int use_light;
   float w_ambient, w_diffuse;
   int light_mode;          /* 0: light_dir = (0,0,1) (the default); 1: light_vec = -light_dir; 2: light_vec = light_pos (light_dir=None) */
@@ -256,6 +262,8 @@ int fp_prof_read(fp_ctx *ctx, const char *kernel_class, double *total_ms, int64_
  * class overlap on two streams): FLOPs / busy time is the rate the chip sustains on the class */
 int fp_prof_read_busy(fp_ctx *ctx, const char *kernel_class, double *busy_ms);
 int fp_prof_reset(fp_ctx *ctx);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

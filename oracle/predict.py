@@ -138,21 +138,25 @@ def pose_update(cfg, poseA, trans, rot, mesh_diameter, tf_to_crops=None, Ks=None
 
 
 @torch.no_grad()
-def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_tensors, mesh_diameter, iteration=5, chunk=16, trace=None, autocast=False):
-  """PoseRefinePredictor.predict (predict_pose_refine.py:150-237), fp32; autocast=True: the network under
+def refine_predict(cfg, sd, rgb, depth, K, ob_in_cams, xyz_map, mesh_tensors, mesh_diameter, iteration=5, chunk=16, trace=None, autocast=False, recipe=None):
+  """PoseRefinePredictor.predict (predict_pose_refine.py:150-237), fp32; recipe='d16': the network with the HIP kernels' rounding points
+  (nets.refine_forward_d16; everything outside the network stays the fp32 oracle); autocast=True: the network under
   torch.autocast('cpu', dtype=torch.float16) - the reference's own precision on the GPU (predict_pose_refine.py:190) - with the
   outputs taken back to fp32 for the pose update, as the reference does (`output[k].float()`, :195-200)."""
   B_in_cams = torch.as_tensor(ob_in_cams, dtype=torch.float32)
   rgb_t = torch.as_tensor(rgb, dtype=torch.float32)
   depth_t = torch.as_tensor(depth, dtype=torch.float32)
   xyz_t = torch.as_tensor(xyz_map, dtype=torch.float32)
+  folded = nets.fold_trunk_d16(sd, 'encodeA', 'encodeAB', cfg['use_BN']) if recipe == 'd16' else None
   for it in range(iteration):
     pd = make_crop_data_batch_refine(cfg, B_in_cams, mesh_tensors, rgb_t, depth_t, K, xyz_t, mesh_diameter)
     outs = []
     for b in range(0, len(B_in_cams), chunk):
       A = torch.cat([pd['rgbAs'][b:b + chunk], pd['xyz_mapAs'][b:b + chunk]], dim=1).float()
       Bt = torch.cat([pd['rgbBs'][b:b + chunk], pd['xyz_mapBs'][b:b + chunk]], dim=1).float()
-      if autocast:
+      if recipe == 'd16':
+        o = nets.refine_forward_d16(sd, A, Bt, cfg['use_BN'], folded=folded)
+      elif autocast:
         with torch.autocast('cpu', dtype=torch.float16):
           o = nets.refine_forward(sd, A, Bt, cfg['use_BN'])
         o = {k: v.float() for k, v in o.items()}

@@ -14,6 +14,7 @@ tests/cases.py, shared with the tests.
                                                 # per-hypothesis features do not depend on it) that maximises the smallest
                                                 # top-1 / top-2 logit margin over all cases; prints the ranking
   python tests/golden/gen_fullsize.py write     # fixture with synthetic.py's current default tail seed
+  python tests/golden/gen_fullsize.py d16       # adds <case>/poses_iter_d16 (the refine chain with the HIP kernels' rounding points, oracle/nets.py refine_forward_d16)
   python tests/golden/gen_fullsize.py ac16      # adds <case>/poses_iter_ac16 (the refine chain with the network under CPU autocast fp16) to the fixture
 
 The chosen tail seed is the default of foundationpose_amd.synthetic.make_score_state_dict; fullsize.npz records, per case,
@@ -184,7 +185,7 @@ def stage_write():
   path = os.path.join(HERE, 'fullsize.npz')
   if os.path.exists(path):                       # (the autocast chains of stage 'ac16' do not depend on the tail seed: kept)
     old = np.load(path)
-    out.update({k: old[k] for k in old.files if k.endswith('_ac16') and k not in out})
+    out.update({k: old[k] for k in old.files if (k.endswith('_ac16') or k.endswith('_d16')) and k not in out})
   np.savez_compressed(path, **out)
   print('wrote', path, f'{os.path.getsize(path) / 1e6:.2f} MB')
 
@@ -192,15 +193,27 @@ def stage_write():
 AC16_CASES = ('c1', 'c3_1', 'c3_2', 'c3_3')
 
 
+def stage_d16():
+  """The oracle's refine chain with the PRODUCT'S numeric recipe (oracle/nets.py refine_forward_d16: fp16 roundings where the HIP kernels round,
+  fp32 accumulation) through the same five full-gain iterations -> `<case>/poses_iter_d16`.  The GPU test compares the HIP chain with THIS
+  chain on all 252 hypotheses: what separates them is the order of fp32 sums only, so agreement far inside the fp16-vs-fp32 scatter shows
+  that the HIP path differs from the fp32 oracle by precision, not by logic."""
+  _stage_chain('d16', dict(recipe='d16'))
+
+
 def stage_ac16():
-  """The reference's OWN precision chained: the oracle's refine loop with the network under torch.autocast('cpu', float16) (what
-  predict_pose_refine.py:190 runs on the GPU) through the same five full-gain iterations, for configs[1] and the three other objects of configs[3].
-  Added to the existing fixture as `<case>/poses_iter_ac16` (the other keys are left as they are): the full-gain chain test measures
-  the HIP path's scatter against THIS chain's scatter around the fp32 chain.  ~7 min per case on 8 cores."""
+  _stage_chain('ac16', dict(autocast=True))
+
+
+def _stage_chain(tag, kw):
+  """The oracle's refine loop with the network in another precision through the same five full-gain iterations, for configs[1] and the three
+  other objects of configs[3]; added to the existing fixture as `<case>/poses_iter_<tag>` (the other keys are left as they are).
+  ac16: the reference's OWN precision - torch.autocast('cpu', float16), what predict_pose_refine.py:190 runs on the GPU; the full-gain chain
+  test measures the HIP path's scatter against THIS chain's scatter around the fp32 chain.  d16: see stage_d16.  ~7 min per case on 8 cores."""
   from foundationpose_amd import synthetic as S
   from oracle import predict as OP
   from tests import cases
-  torch.set_num_threads(os.cpu_count())
+  torch.set_num_threads(int(os.environ.get('FP_GEN_THREADS', os.cpu_count())))
   path = os.path.join(HERE, 'fullsize.npz')
   out = dict(np.load(path))
   for name in AC16_CASES:
@@ -211,15 +224,15 @@ def stage_ac16():
     t0 = time.time()
     trace = []
     poses = OP.refine_predict(rcfg, rsd, sc['rgb'], c['depth'], sc['K'], c['poses0'], c['xyz_map'], sc['mt'], sc['diameter'],
-                              iteration=c['iteration'], chunk=16, trace=trace, autocast=True)
+                              iteration=c['iteration'], chunk=16, trace=trace, **kw)
     per_iter = np.stack([t['poseA'].numpy() for t in trace[1:]] + [poses.numpy()]).astype(np.float32)
-    out[f'{name}/poses_iter_ac16'] = per_iter
+    out[f'{name}/poses_iter_{tag}'] = per_iter
     d = np.abs(per_iter - out[f'{name}/poses_iter']).reshape(per_iter.shape[0], per_iter.shape[1], -1).max(2)
-    print(f'{name}: autocast chain in {time.time() - t0:.0f} s; |ac16 - fp32| per iteration: median ' + ' '.join(f'{np.median(x):.1e}' for x in d) +
+    print(f'{name}: {tag} chain in {time.time() - t0:.0f} s; |chain - fp32| per iteration: median ' + ' '.join(f'{np.median(x):.1e}' for x in d) +
           ' max ' + ' '.join(f'{x.max():.1e}' for x in d), flush=True)
   np.savez_compressed(path, **out)
   print('wrote', path, f'{os.path.getsize(path) / 1e6:.2f} MB')
 
 
 if __name__ == '__main__':
-  {'feats': stage_feats, 'track': stage_track, 'tail': stage_tail, 'write': stage_write, 'ac16': stage_ac16}[sys.argv[1]]()
+  {'feats': stage_feats, 'track': stage_track, 'tail': stage_tail, 'write': stage_write, 'ac16': stage_ac16, 'd16': stage_d16}[sys.argv[1]]()

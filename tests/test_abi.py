@@ -34,6 +34,16 @@ def test_library_exports_every_symbol(built):
   assert built.lib().fp_version() >= 100
 
 
+def test_only_the_c_abi_is_exported(built):
+  """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table holds the C ABI and nothing else (no C++ helper, no kernel
+  handle that another HIP library in the host process could interpose)."""
+  import subprocess
+  out = subprocess.run(['nm', '-D', '--defined-only', built.LIB_PATH], capture_output=True, text=True, check=True).stdout
+  names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+  assert names and all(n.startswith('fp_') for n in names), [n for n in names if not n.startswith('fp_')][:10]
+  assert sorted(n for n in names if not n.startswith('fp_dbg_')) == header_symbols()
+
+
 def test_product_does_not_import_oracle():
   """The product path must never route through the CPU oracle."""
   pkg = os.path.join(REPO, 'foundationpose_amd')

@@ -35,7 +35,8 @@ def test_depth_to_vis_rules():
   # src/Utils.py:473-476: 'gray' clips before the uint8 cast, 'rgb' does not - a level above 1 (inverse mode, depth nearer than a given zmin)
   # saturates in 'gray' and WRAPS in 'rgb', exactly as (vis * 255).astype(np.uint8) does in the reference
   near = np.array([[0.4, 0.5]], np.float32)                          # zmin / depth = 1.25 -> 318.75 -> uint8 62 ; 1.0 -> 255
-  assert V.depth_to_vis(near, zmin=0.5, mode='gray', inverse=True).tolist() == [[255, 254]] or V.depth_to_vis(near, zmin=0.5, mode='gray', inverse=True)[0, 0] == 255
+  # gray: 1.25 clips to 1.0 -> 255; 0.5 / (0.5 + 1e-8) is exactly 1.0 in float32 (1e-8 is below half an ulp of 0.5) -> 255
+  assert V.depth_to_vis(near, zmin=0.5, mode='gray', inverse=True).tolist() == [[255, 255]]
   wrapped = (np.float32(0.5) / (near + np.float32(1e-8)) * 255).astype(np.uint8)
   assert wrapped[0, 0] < 100                                          # the cast wrapped
   assert np.array_equal(V.depth_to_vis(near, zmin=0.5, mode='rgb', inverse=True), V._jet(wrapped))
@@ -91,8 +92,6 @@ def test_get_vis_canvases(tmp_path):
   np.testing.assert_array_equal(first[~label], want[~label])
   green = (first[label] == np.array([0, 255, 0], np.uint8)).all(-1)
   assert 40 < int(green.sum()) < 14 * 48 // 2                     # (the glyphs' pixels, pure green; predict_pose_refine.py:265)
-  right_half = vis[:, half_w + 2 + 2:]
-  assert not ((right_half == np.array([0, 255, 0], np.uint8)).all(-1)).any() or True      # (the refined half carries no labels; renders may hold green pixels of their own)
   refined_again, none = refiner.predict(sc['rgb'], depth, sc['K'], poses, xyz_map, iteration=1, **kw)
   assert none is None and torch.equal(refined, refined_again)
   scores, svis = scorer.predict(sc['rgb'], depth, sc['K'], refined, get_vis=True, **kw)
