@@ -207,16 +207,25 @@ def test_full_gain_chain_on_hypotheses_whose_windows_never_flip(name, full, pred
     assert mh <= 1.5 * mr and ph <= 1.5 * pr and xh <= 1.5 * xr, f'{name}: the HIP chain scatters further from the fp32 chain than 1.5 x the reference fp16 chain'
 
 
+D16_STEP_TOL = 1e-4      # a tenth of POSE_TOL: what the order of fp32 sums may cost one full-gain pass (measured: max 4e-5 over 252 x 5 x 4 objects)
+
+
 @pytest.mark.parametrize('name', cases.STEP_CASES)
-def test_full_gain_chain_equals_the_oracle_with_the_products_roundings(name, full, predictors):
-  """is the divergence of the full-gain chain from the fp32 oracle PRECISION ONLY?  The fixture holds the
-  oracle's own five chained full-gain iterations with the network computed the way the HIP kernels compute it (oracle/nets.py
-  refine_forward_d16: fp16 roundings at the kernels' rounding points, fp32 accumulation; render, crops and pose update stay the fp32 oracle).
-  Products of fp16 values are exact in fp32, so that chain and the HIP chain differ by the ORDER of fp32 sums (and exp2 to an ulp) - a logic
-  difference that gain 0.1 hides would show here as it shows against the fp32 chain.  ALL 252 hypotheses, no subset, every iteration:
-    * the crop window the HIP chain computes for iteration k is identical to the d16 chain's for >= 97 % of the hypotheses, and
-    * on every hypothesis whose windows agreed so far the poses agree to 1e-3 (POSE_TOL; measured: see the printed line);
-    * the HIP chain is several times closer to the d16 chain than either is to the fp32 chain (medians over all 252)."""
+def test_full_gain_passes_equal_the_oracle_with_the_products_roundings(name, full, predictors):
+  """is the divergence of the full-gain chain from the fp32 oracle PRECISION ONLY, or a logic difference that
+  gain 0.1 hides?  The fixture holds the oracle's own five chained full-gain iterations with the network computed the way the HIP kernels
+  compute it (`*/poses_iter_d16`; oracle/nets.py refine_forward_d16: fp16 roundings at the kernels' rounding points, fp32 accumulation;
+  render, crops, pose update stay the fp32 oracle).  Products of fp16 values are exact in fp32, so that network and the HIP network differ
+  by the ORDER of fp32 sums (and exp2 to an ulp) and by nothing else.
+  (a) EVERY pass, ALL 252 hypotheses, no subset, full gain: iteration k of the HIP path from the d16 chain's state after k - 1 iterations
+      (so both sides see the same crop window and the same pixels) against the d16 chain's state after k: max over the 252 poses < 1e-4 -
+      ten times inside the tolerance and ~7 x closer than the fp32 oracle is (1.2-1.4e-4, test_every_iteration_one_step_...).  A logic
+      difference at full gain would show here exactly as it shows against the fp32 chain; precision is all that is left.
+  (b) CHAINED from the start hypotheses: two chains that differ by 1e-5 per pass still separate - the untrained network doubles a
+      difference per iteration and the rounded crop window (src/Utils.py:577-621) flips for ~3 % of the hypotheses per iteration (a 1.3e-5 m
+      difference is 0.02 px) - so no chain of ANY two implementations stays within 1e-3 on all 252 for five iterations.  Asserted on all 252:
+      at every iteration the HIP chain is at least 3 x closer (median) to the d16 chain than to the fp32 chain, and it shares its crop
+      windows with the d16 chain on more hypotheses than the d16 chain does with the fp32 chain."""
   from oracle import geometry as G
   r_step, _, _ = predictors
   key = f'{name}/poses_iter_d16'
@@ -227,25 +236,37 @@ def test_full_gain_chain_equals_the_oracle_with_the_products_roundings(name, ful
   kw = dict(rgb=sc['rgb'], depth=c['depth'], K=sc['K'], mesh_tensors=mt, mesh_diameter=sc['diameter'])
   d16, f32 = full[key], full[f'{name}/poses_iter']
   n = len(c['poses0'])
-  assert d16.shape == (5, n, 4, 4)
+  assert d16.shape == (5, n, 4, 4) and n == 252
+  flat = lambda d: np.abs(d).reshape(n, -1).max(1)
+  # (a) one pass from the d16 chain's own state, all 252
+  for it in range(1, 6):
+    start = c['poses0'] if it == 1 else d16[it - 2]
+    got, _ = r_step.predict(ob_in_cams=start, xyz_map=c['xyz_map'], iteration=1, **kw)
+    err = flat(got.cpu().numpy() - d16[it - 1])
+    moved = flat(d16[it - 1] - start)
+    print(f'{name}: pass {it} at full gain from the d16 chain\'s state, all {n} hypotheses: |hip - d16| median {np.median(err):.2e} max {err.max():.2e} '
+          f'(the pass moves the poses by median {np.median(moved):.2e})')
+    assert np.median(moved) > 5 * D16_STEP_TOL                      # millimetre steps that depend on the crops
+    assert err.max() < D16_STEP_TOL, f'{name}: pass {it}: more than the order of fp32 sums explains'
+  # (b) chained
   window = lambda p: G.compute_crop_window_tf_batch(p, sc['K'], crop_ratio=r_step.cfg['crop_ratio'], out_size=(160, 160),
                                                     mesh_diameter=sc['diameter']).numpy()
-  same = np.ones(n, dtype=bool)
+  same_hd = np.ones(n, dtype=bool)
+  same_df = np.ones(n, dtype=bool)
   gpu_prev = c['poses0']
   for it in range(1, 6):
     d_prev = c['poses0'] if it == 1 else d16[it - 2]
-    same &= (window(gpu_prev) == window(d_prev)).reshape(n, -1).all(1)
+    f_prev = c['poses0'] if it == 1 else f32[it - 2]
+    same_hd &= (window(gpu_prev) == window(d_prev)).reshape(n, -1).all(1)
+    same_df &= (window(d_prev) == window(f_prev)).reshape(n, -1).all(1)
     got, _ = r_step.predict(ob_in_cams=c['poses0'], xyz_map=c['xyz_map'], iteration=it, **kw)
     gpu_prev = got.cpu().numpy()
-    err = np.abs(gpu_prev - d16[it - 1]).reshape(n, -1).max(1)
-    e32 = np.abs(gpu_prev - f32[it - 1]).reshape(n, -1).max(1)
-    d32 = np.abs(d16[it - 1] - f32[it - 1]).reshape(n, -1).max(1)
-    print(f'{name}: {it} chained full-gain iteration(s), all {n} hypotheses: windows identical to the d16 chain so far on {int(same.sum())}; on them '
-          f'|hip - d16| median {np.median(err[same]):.2e} max {err[same].max():.2e}; over all {n}: median |hip - d16| {np.median(err):.2e}, '
-          f'|hip - fp32| {np.median(e32):.2e}, |d16 - fp32| {np.median(d32):.2e}')
-    assert same.sum() >= 0.97 * n, f'{name}: iteration {it}: the HIP chain and the d16 chain disagree on more than 3 % of the crop windows'
-    assert err[same].max() < POSE_TOL, f'{name}: iteration {it}: same windows, poses differ by more than the summation order explains'
-    assert np.median(err) < 0.35 * min(np.median(e32), np.median(d32)), f'{name}: iteration {it}: no closer to the d16 chain than to the fp32 chain'
+    e_hd, e_hf, e_df = flat(gpu_prev - d16[it - 1]), flat(gpu_prev - f32[it - 1]), flat(d16[it - 1] - f32[it - 1])
+    print(f'{name}: {it} chained full-gain iteration(s), all {n}: median |hip - d16| {np.median(e_hd):.2e}, |hip - fp32| {np.median(e_hf):.2e}, '
+          f'|d16 - fp32| {np.median(e_df):.2e}; crop windows never differed: hip/d16 on {int(same_hd.sum())}, d16/fp32 on {int(same_df.sum())}; '
+          f'on the {int(same_hd.sum())}: |hip - d16| max {e_hd[same_hd].max():.2e}')
+    assert np.median(e_hd) < min(np.median(e_hf), np.median(e_df)) / 3, f'{name}: {it} chained iterations: not closer to the d16 chain than to the fp32 chain'
+    assert same_hd.sum() >= same_df.sum(), f'{name}: {it} chained iterations: more window flips against the d16 chain than precision causes'
 
 
 def test_argmax_over_tail_seeds_nobody_selected(full, predictors):

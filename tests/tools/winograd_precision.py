@@ -34,10 +34,29 @@ def wino_conv3x3(x, w, b):
   return y if b is None else y + b.reshape(1, -1, 1, 1)
 
 
+def wino_conv3x3_rows(x, w, b):
+  """F(2,3) ALONG ROWS only (the form of csrc/conv_wino.hip): per output pair (x0, x0+1) and kernel row ky, v = Bt d over the four input
+  columns x0-1 .. x0+2 (ONE fp16 add each, as v_pk_add_f16 computes it), u = G g rounded to fp16 from the fp32 weights, products
+  accumulated in fp32 over (ky, ci), y = At m in fp32."""
+  N, C, H, W = x.shape
+  t = F.pad(h16(x), (1, 1, 1, 1)).unfold(3, 4, 2)                                # (N,C,H+2,W/2,4)
+  V = h16(torch.einsum('ij,nchwj->nchwi', BT, t))                                 # (N,C,H+2,W/2,4)
+  U = h16(torch.einsum('ij,ockj->ocki', GM, w))                                   # (O,C,3,4)
+  out = []
+  for n in range(N):
+    M = sum(torch.einsum('chwi,oci->ohwi', V[n][:, ky:ky + H], U[:, :, ky]) for ky in range(3))      # (O,H,W/2,4)
+    Y = torch.einsum('ji,ohwi->ohwj', AT, M)                                       # (O,H,W/2,2)
+    out.append(Y.reshape(w.shape[0], H, W))
+  y = torch.stack(out)
+  return y if b is None else y + b.reshape(1, -1, 1, 1)
+
+
 def make_conv(mode):
   def conv2d(x, w, b=None, stride=1, padding=0, *a, **k):
     if mode == 'W' and w.shape[-1] == 3 and stride == 1 and x.shape[-1] % 2 == 0:
       return wino_conv3x3(x, w, b)
+    if mode == 'W1' and w.shape[-1] == 3 and stride == 1 and x.shape[-1] % 2 == 0:
+      return wino_conv3x3_rows(x, w, b)
     return _conv2d(h16(x), h16(w), b, stride, padding, *a, **k)
   return conv2d
 
@@ -68,9 +87,9 @@ def main():
   B = torch.cat([pd['rgbBs'], pd['xyz_mapBs']], 1).float()
   sd = S.make_refine_state_dict(0)
   with torch.no_grad():
-    out = {m: run(m, sd, A, B) for m in ('R', 'D', 'W')}
+    out = {m: run(m, sd, A, B) for m in ('R', 'D', 'W', 'W1')}
   pose = {m: OP.pose_update(cfg, pd['poseA'], out[m]['trans'], out[m]['rot'], sc['diameter'])[0] for m in out}
-  for a, b in (('D', 'R'), ('W', 'R'), ('W', 'D')):
+  for a, b in (('D', 'R'), ('W', 'R'), ('W', 'D'), ('W1', 'R'), ('W1', 'D')):
     dt = float((out[a]['trans'] - out[b]['trans']).abs().max()); dr = float((out[a]['rot'] - out[b]['rot']).abs().max())
     dp = float((pose[a] - pose[b]).abs().max())
     print(f'{a} vs {b}: max |d trans| {dt:.2e}  max |d rot| {dr:.2e}  (outputs are O({float(out["R"]["trans"].abs().max()):.2f}))  pose after one update {dp:.2e}')
