@@ -230,8 +230,10 @@ def cpu_baseline():
   from oracle.predict import OracleFoundationPose
   from foundationpose_amd import synthetic as S
   from foundationpose_amd.config import REFINE_DEFAULT, SCORE_DEFAULT
-  # the GPU box exposes 256 logical CPUs but one GPU's share is 16: more threads only oversubscribe
-  cores = min(os.cpu_count() or 1, 16)
+  # the GPU box exposes 256 logical CPUs but one GPU's share is 16 (8 GPUs per host; gpurun's process guard sizes worker pools to 16 for
+  # one GPU): more threads only oversubscribe cores that belong to the other seven boxes' jobs
+  host_cpus = os.cpu_count() or 1
+  cores = min(host_cpus, 16)
   os.environ['OMP_NUM_THREADS'] = str(cores)
   torch.set_num_threads(cores)
   sc = util.scene(0)
@@ -255,7 +257,8 @@ def cpu_baseline():
   med = sorted(t32)[2]
   return dict(value=n_s / dt, unit='pose-hypotheses/sec', cores=cores, kind='port',
               sample=f'{n_s} hypotheses of the same scene (half of configs[1]), est_refine_iter={ITER} + score, one timed pass after a warm-up '
-                     f'pass: oracle/ (torch-CPU fp32 nets + C/OpenMP rasteriser), {dt:.1f} s wall incl. depth filtering',
+                     f'pass: oracle/ (torch-CPU fp32 nets + C/OpenMP rasteriser), {dt:.1f} s wall incl. depth filtering; {cores} of the host\'s {host_cpus} logical '
+                     f'CPUs: one GPU\'s share of an 8-GPU host (the other cores belong to the other seven boxes\' jobs)',
               configs0=dict(value=32 / med, unit='pose-hypotheses/sec', cores=cores, seconds_per_register=med,
                             hypothesis_passes_per_sec=32 * 2 / med,
                             sample='BASELINE configs[0] / SURVEY.md 8(d): 32 hypotheses, est_refine_iter=1 + score (2 network passes per hypothesis), '
@@ -381,14 +384,16 @@ def main(argv=None):
   timed_steps(single, args.steps, barrier, device, world)
   ctx.prof_enable(False)
   classes = {}
-  for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'heads_wall', 'render'):
+  for c in ('conv3x3_halo', 'conv3x3_s2', 'conv7x7', 'linear', 'attention', 'heads_wall', 'render', 'crop'):
     r = ctx.prof_read(c)
     if r['launches']:
       # ms_per_step: sum of the launch spans; busy_ms_per_step: time with at least one launch of the class executing (smaller where
       # launches of the class overlap on two streams: the two half-batch trunks, the two RefineNet heads); tflops = FLOPs / busy time
       classes[c] = {'ms_per_step': r['total_ms'] / args.steps, 'busy_ms_per_step': r['busy_ms'] / args.steps,
                     'launches_per_step': r['launches'] / args.steps,
-                    'tflops': (r['flops'] / (r['busy_ms'] * 1e-3) / 1e12) if r['flops'] and r['busy_ms'] > 0 else None}
+                    'tflops': (r['flops'] / (r['busy_ms'] * 1e-3) / 1e12) if r['flops'] and r['busy_ms'] > 0 and c not in ('render', 'crop') else None}
+      if c in ('render', 'crop'):          # these two report BYTES WRITTEN as their work figure
+        classes[c]['bytes_written_per_step'] = r['flops'] / args.steps
   # the same K steps with the per-launch events off (how much the events cost), and where a step's time goes on this rank
   dt_noprof, _ = timed_steps(single, args.steps, barrier, device, world)
   marks = []
@@ -465,6 +470,19 @@ def main(argv=None):
       'ms_per_step_events_off': dt_noprof / args.steps * 1e3,
       'phases_ms_per_rank': [dict(zip(('local', 'allgather', 'tail'), [float(x) for x in p.tolist()])) for p in ph_all],
     }
+    # SURVEY 8(d) / BASELINE.md section 4: the step as a fraction of the MFMA roofline, and the render + crop stage against the HBM roofline
+    step_flops = 141.7e9 * N_HYP                  # (5 x 23.95 + 21.94) GFLOP per hypothesis
+    out['roofline']['step_frac'] = step_flops / (dt / args.steps) / 1e12 / PEAK_F16_TFLOPS
+    out['roofline']['step_tflops'] = step_flops / (dt / args.steps) / 1e12
+    rc = [classes[c] for c in ('render', 'crop') if c in classes]
+    if len(rc) == 2:
+      b = sum(c['bytes_written_per_step'] for c in rc)
+      t = sum(c['busy_ms_per_step'] for c in rc) * 1e-3
+      out['hbm_stage'] = {'bound': 'hbm', 'kernels': 'classify_faces_kernel + render_kernel (side A) and crop_observed_kernel (side B): the fp16 network tensor of every pass',
+                          'bytes_written_per_step': b, 'busy_ms_per_step': t * 1e3, 'achieved': b / t / 1e9 if t > 0 else None, 'peak': 8000.0, 'unit': 'GB/s',
+                          'frac': (b / t / 1e9 / 8000.0) if t > 0 else None,
+                          'note': 'algorithmic bytes (SURVEY 8(d): 2 x 160 x 160 x 16 B per hypothesis and pass) over the busy time of the two classes; the rasteriser is '
+                                  'bound by lane utilisation in its classification and triangle passes, not by these writes (DESIGN.md section 5)'}
     out['kernel_classes'] = classes       # HIP-event time per kernel class, from an untimed pass of the same K steps
     out['kernel_classes_note'] = ('ms_per_step = sum of the launch spans, busy_ms_per_step = time with at least one launch of the class executing. The classes '
                                   'OVERLAP: the trunk runs as two half batches on two streams (two launches of a convolution class in flight: spans sum to about '

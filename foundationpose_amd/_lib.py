@@ -80,6 +80,7 @@ _PROTOS = {
   'fp_conv2d_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
   'fp_token_linear_f16': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_head_mlp_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 8 + [c_void_p, c_void_p]),
+  'fp_conv3x3_wino_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_attention_f16': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
   'fp_cluster_poses': (c_int, [c_float, c_float, c_void_p, c_int, c_void_p, c_int, c_void_p]),
   'fp_prof_enable': (c_int, [c_void_p, c_int]),

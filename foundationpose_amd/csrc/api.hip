@@ -64,7 +64,7 @@ static int g_one_chain = 0;      // FP_ONE_CHAIN=1: the two sides of encodeA as 
 
 int fp_set_kernel_attributes(fp_ctx *ctx) {
   std::vector<KernelLds> v;
-  conv_kernel_lds(v), conv_halo_kernel_lds(v), conv_s1b_kernel_lds(v), conv_s2_kernel_lds(v), stem_kernel_lds(v);
+  conv_kernel_lds(v), conv_halo_kernel_lds(v), conv_s1b_kernel_lds(v), conv_wino_kernel_lds(v), conv_s2_kernel_lds(v), stem_kernel_lds(v);
   tok_gemm_kernel_lds(v), tok_qkv_kernel_lds(v), head_mlp_kernel_lds(v), attn_kernel_lds(v), raster_kernel_lds(v);
   FP_CHECK_HIP(hipSetDevice(ctx->device));
   for (const KernelLds &k : v)
@@ -425,6 +425,7 @@ extern "C" int fp_crop_observed(fp_ctx *ctx, const float *d_rgb, const float *d_
   a.out_fmt = out_fmt;
   a.mesh_diameter = (float)mesh_diameter;
   a.out = d_out;
+  ProfScope ps(ctx, (hipStream_t)stream, "crop", (double)N * out_h * out_w * (out_fmt == 1 ? 16.0 : 24.0));      // bytes written
   return launch_crop_observed(a, (hipStream_t)stream);
 }
 
@@ -833,6 +834,45 @@ extern "C" int fp_conv3x3_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, int 
   int rc = pk ? s2_pack_weights(a.w, C, C, a.Kpad, pk, (hipStream_t)stream, 2, 1) : FP_ENOMEM;
   a.wpk = pk;
   if (rc == FP_OK) rc = launch_conv_s1b(ctx, a, (hipStream_t)stream);
+  ctx->arena.off = mark;
+  return rc;
+}
+
+extern "C" int fp_conv3x3_wino_f16(fp_ctx *ctx, const void *d_in, int Nimg, int HW, int Cin, int Cout, const float *h_weight, const float *d_bias,
+                                   const void *d_res, int relu, void *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_in && h_weight && d_bias && d_out && Nimg >= 0, "fp_conv3x3_wino_f16: bad argument");
+  FP_REQUIRE((HW == 40 || HW == 20) && Cin % 32 == 0 && Cin >= 64 && Cout % 64 == 0, "fp_conv3x3_wino_f16: HW=%d Cin=%d Cout=%d unsupported", HW, Cin, Cout);
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = (const f16 *)d_in;
+  a.bias = d_bias;
+  a.res = (const f16 *)d_res;
+  a.out = d_out;
+  a.Nimg = Nimg;
+  a.H = a.W = a.Ho = a.Wo = HW;
+  a.Cin = Cin, a.Cout = Cout;
+  a.KH = a.KW = 3;
+  a.stride = 1;
+  a.pad = 1;
+  a.Kpad = 9 * Cin;
+  a.M = Nimg * HW * HW;
+  a.relu = relu;
+  a.out_ld = Cout;
+  a.split_m = 0x7fffffff;
+  a.post_period = 1;
+  a.tokens = 400;
+  if (a.M == 0) return FP_OK;
+  std::vector<f16> hu(wino_packed_halfs(Cout, Cin));
+  wino_pack_weights(h_weight, nullptr, Cout, Cin, hu.data());
+  const size_t bytes = hu.size() * sizeof(f16);
+  FP_TRY(fp_arena_ensure(ctx, bytes + 4096));
+  const size_t mark = ctx->arena.off;
+  f16 *pk = (f16 *)ctx->arena.take(bytes);
+  int rc = pk ? FP_OK : FP_ENOMEM;
+  if (rc == FP_OK && hipMemcpyAsync(pk, hu.data(), bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) rc = FP_EHIP;
+  a.wwino = pk;
+  if (rc == FP_OK) rc = launch_conv_wino(ctx, a, (hipStream_t)stream);
+  if (rc == FP_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = FP_EHIP;      // (hu is a host temporary)
   ctx->arena.off = mark;
   return rc;
 }

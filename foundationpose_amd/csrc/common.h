@@ -220,6 +220,7 @@ struct KernelLds {
 void conv_kernel_lds(std::vector<KernelLds> &v);        // conv.hip
 void conv_halo_kernel_lds(std::vector<KernelLds> &v);   // conv_halo.hip
 void conv_s1b_kernel_lds(std::vector<KernelLds> &v);    // conv_s1b.hip
+void conv_wino_kernel_lds(std::vector<KernelLds> &v);   // conv_wino.hip
 void conv_s2_kernel_lds(std::vector<KernelLds> &v);     // conv_s2.hip
 void stem_kernel_lds(std::vector<KernelLds> &v);        // stem.hip
 void tok_gemm_kernel_lds(std::vector<KernelLds> &v);    // tok_gemm.hip
@@ -247,6 +248,8 @@ struct ConvArgs {
   int ksplit = 0;
   // 3x3 stride-2 layers: the weights in the fragment order of conv_s2.hip (s2_pack_weights); nullptr: the implicit-GEMM kernel runs
   const f16 *wpk = nullptr;
+  // 3x3 stride-1 layers: the Winograd F(2,3)-along-rows image of the fp32 weights (conv_wino.hip: wino_pack_weights); nullptr: the direct kernels run
+  const f16 *wwino = nullptr;
 };
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 // conv_s2.hip: band-in-LDS form of the 3x3 stride-2 layers
@@ -259,6 +262,13 @@ int launch_conv_s2(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 // conv_s1b.hip: band-in-LDS form of the 128 -> 128 stride-1 layers on 40x40 maps (bit-identical to the halo kernel; FP_C128_BAND=0: off)
 bool s1b_supported(const ConvArgs &a);
 int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
+
+// conv_wino.hip: Winograd F(2,3) along rows for the 3x3 stride-1 layers (its own numerics: transformed weights and inputs in fp16)
+bool conv_wino_supported(const ConvArgs &a);
+size_t wino_packed_halfs(int Cout, int Cin);
+void wino_pack_weights(const float *w_oihw, const float *scale_per_cout, int Cout, int Cin, f16 *out_host);
+int launch_conv_wino(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
+int fp_wino_mode();            // conv.hip: FP_WINO (0: off - the default until measured; 1: every supported 3x3 stride-1 launch)
 
 // Column of token t inside the transposed V image [b][4][128][416].  Within each group of 16 tokens the order is
 // {0-3, 8-11, 4-7, 12-15}: the 8 keys that one lane half of the attention kernel's P^T operand carries (the S^T

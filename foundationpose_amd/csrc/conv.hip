@@ -512,6 +512,11 @@ int launch_conv_halo(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 bool stem_supported(const ConvArgs &a);                     // stem.hip
 int launch_stem(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
+int fp_wino_mode() {
+  static const int m = getenv("FP_WINO") ? atoi(getenv("FP_WINO")) : 0;
+  return m;
+}
+
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   FP_REQUIRE(a.Cin == 8 || a.Cin % 32 == 0, "conv: Cin=%d must be 8 or a multiple of 32", a.Cin);
   FP_REQUIRE(a.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", a.Cout);
@@ -524,6 +529,7 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const bool halo = conv_halo_supported(a);
   const char *cls = halo ? "conv3x3_halo" : (a.KW == 3) ? "conv3x3_s2" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
+  if (halo && fp_wino_mode() != 0 && conv_wino_supported(a)) return launch_conv_wino(ctx, a, s);
   {
     static const int band = getenv("FP_C128_BAND") ? atoi(getenv("FP_C128_BAND")) : 1;   // conv_s1b.hip (bit-identical to the halo kernel); 0: off, 2: also the 256 -> 256 layers
     // ... from the batch size on at which the general kernel needs more than one round of its 512-pixel tiles (82 images on 256 CUs): below,

@@ -11,6 +11,7 @@
 struct ConvW {
   f16 *w = nullptr;
   f16 *wpk = nullptr;     // 3x3 stride-2 layers: the same weights in the fragment order of conv_s2.hip
+  f16 *wwino = nullptr;   // 3x3 stride-1 layers from 128 channels on: the Winograd image of the fp32 weights (conv_wino.hip)
   float *bias = nullptr;
   int Cin = 0, Cout = 0, K = 1, Kpad = 0, stride = 1;
 };
@@ -137,6 +138,12 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
   out->stride = stride;
   FP_TRY(upload(net, hw, &out->w));
   FP_TRY(upload(net, hb, &out->bias));
+  if (K == 3 && stride == 1 && CinP >= 128 && CinP % 32 == 0 && Cout % 64 == 0 && fp_wino_mode() != 0) {
+    // Winograd F(2,3) along rows: u = G g from the fp32 BN-folded weights, rounded to fp16 once
+    std::vector<f16> hu(wino_packed_halfs(Cout, CinP));
+    wino_pack_weights(w->data, scale.data(), Cout, Cin, hu.data());
+    FP_TRY(upload(net, hu, &out->wwino));
+  }
   // fragment-ordered copy for the band kernels: the 3x3 stride-2 layers (conv_s2.hip) and the 128 -> 128 / 256 -> 256 stride-1 layers, which run on 40x40 maps (conv_s1b.hip)
   if (K == 3 && (stride == 2 || (stride == 1 && CinP == Cout && (Cout == 128 || Cout == 256))) && CinP % 16 == 0 && s2_ct_for(Cout) != 0) {
     void *pk = nullptr;
@@ -319,6 +326,7 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
   a.in = c.in;
   a.w = w.w;
   a.wpk = w.wpk;
+  a.wwino = w.wwino;
   a.bias = w.bias;
   a.res = c.res;
   a.post_add = c.post_add;

@@ -786,7 +786,8 @@ static int launch_render_one(fp_ctx *ctx, const RenderArgs &a_in, int plan_n, hi
   int *count = (int *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes);
   unsigned *listA = (unsigned *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes + pl.count_bytes);
   unsigned *listB = (unsigned *)(sc + pl.c_bytes + pl.b_bytes + pl.a_bytes + pl.count_bytes + pl.list_bytes);
-  ProfScope ps(ctx, s, "render", 0);
+  // (profiling: the class' work figure is BYTES WRITTEN - the fused fp16 net tensor, or the API's fp32 maps - for the HBM-stage line of bench.py)
+  ProfScope ps(ctx, s, "render", a.net_out ? (double)a.N * a.Ho * a.Wo * 16.0 : (double)a.N * a.Ho * a.Wo * 40.0);
   static const bool two_launches = getenv("FP_RENDER_PREPASS2") != nullptr;       // A/B knob: vertex pre-pass and classification as two launches (identical images)
   // fused where one workgroup per hypothesis classifies (G == 1: from 64 hypotheses on): 220 -> 210 us at 252 hypotheses, 144 -> 136 at 126; with
   // the faces of a hypothesis cut into G ranges every range's workgroup would redo the vertex pass (32 hypotheses: 70 -> 73 us, 1: 32 -> 34)

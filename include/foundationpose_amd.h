@@ -222,6 +222,12 @@ int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int W, int Cin
  * kernel behind fp_conv2d_f16. */
 int fp_conv3x3_band_f16(fp_ctx *ctx, const void *d_in, int Nimg, int C, const void *d_w_packed, const float *d_bias, const void *d_res,
                         int relu, void *d_out, void *stream);
+/* The Winograd F(2,3)-along-rows form of a 3x3 stride-1 / pad-1 convolution on HW x HW maps (HW = 40 | 20; csrc/conv_wino.hip), the same
+ * ResnetBasicBlock convolutions: 2/3 of the matrix work.  h_weight: HOST fp32 (Cout, Cin, 3, 3) - the transformed weights u = G g are
+ * rounded to fp16 once from fp32; in NHWC fp16; out = act(conv + bias [+ res]).  Its own numerics (u and v = B^T d in fp16): compared with
+ * the fp32 convolution at a tolerance, not bit for bit with fp_conv2d_f16.  Synchronises the stream. */
+int fp_conv3x3_wino_f16(fp_ctx *ctx, const void *d_in, int Nimg, int HW, int Cin, int Cout, const float *h_weight, const float *d_bias,
+                        const void *d_res, int relu, void *d_out, void *stream);
 /* fused multi-head self-attention core, 4 heads x 128: qk [M][1024] fp16 (q|k), vt [B][4][128][416] fp16 -> out [M][512] fp16.
  * vt is V transposed, token t of a hypothesis in column (t & ~15) | ((t>>2 & 1) << 3) | ((t>>3 & 1) << 2) | (t & 3)
  * (tokens of a group of 16 in the order 0-3, 8-11, 4-7, 12-15); columns of tokens >= T must hold zeros. */

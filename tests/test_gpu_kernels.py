@@ -470,6 +470,45 @@ def test_band_kernel_equals_halo_kernel(fp, N, C, use_res, relu):
     assert err <= 2e-3 * float(ref.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize('shape', [(3, 40, 128, 128, False, True), (5, 40, 256, 256, True, True), (7, 20, 512, 512, True, True), (2, 20, 512, 512, False, False),
+                                   (9, 40, 128, 256, True, True), (33, 20, 512, 512, True, True), (13, 40, 256, 256, False, True)])
+def test_conv_winograd_rows_vs_fp32_reference(fp, shape):
+  """conv_wino.hip (F(2,3) along rows, 2/3 of the matrix work) against torch's fp32 conv2d on the same fp16 activations and fp32 weights.
+  The transformed weights u = G g and the transformed inputs v = B^T d are fp16, so the error is NOT only accumulation order: tolerance
+  3e-3 of the output scale (the direct kernel: 2e-3 on fp16-rounded weights) - and the emulation of exactly these roundings in plain torch
+  (tests/tools/winograd_precision.wino_conv3x3_rows) has to agree to summation order + the output rounding.  Batches of 2 .. 33 images:
+  tiles that start anywhere in a row, cross image boundaries (20x20: up to three images per 512-pixel tile) and end past the tensor."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  from tests.tools.winograd_precision import wino_conv3x3_rows
+  N, HW, Cin, Cout, use_res, relu = shape
+  g = torch.Generator().manual_seed(sum(int(v) for v in shape))
+  x = torch.randn((N, Cin, HW, HW), generator=g).half().relu()
+  w = torch.randn((Cout, Cin, 3, 3), generator=g) * (2.0 / (Cin * 9)) ** 0.5
+  b = torch.randn((Cout,), generator=g) * 0.1
+  ref = torch.nn.functional.conv2d(x.float(), w, b, padding=1)
+  emu = wino_conv3x3_rows(x.float(), w, b)
+  res = None
+  if use_res:
+    res = torch.randn(ref.shape, generator=g).half()
+    ref, emu = ref + res.float(), emu + res.float()
+  if relu:
+    ref, emu = torch.relu(ref), torch.relu(emu)
+  x_d = x.permute(0, 2, 3, 1).contiguous().cuda()
+  res_d = res.permute(0, 2, 3, 1).contiguous().cuda() if use_res else None
+  b_d = b.cuda()
+  out = torch.full((N, HW, HW, Cout), float('nan'), dtype=torch.float16, device='cuda')
+  wc = w.contiguous()
+  check(lib().fp_conv3x3_wino_f16(fp['ctx'].handle, ptr(x_d), N, HW, Cin, Cout, wc.data_ptr(), ptr(b_d), ptr(res_d) if use_res else None,
+                                  1 if relu else 0, ptr(out), stream_ptr()))
+  got = out.float().permute(0, 3, 1, 2).cpu()
+  assert not bool(torch.isnan(got).any())
+  scale = float(ref.abs().max())
+  e_ref, e_emu = float((got - ref).abs().max()), float((got - emu.half().float()).abs().max())
+  print(f'{shape}: |wino - fp32| {e_ref:.2e}, |wino - torch emulation of its roundings| {e_emu:.2e} (output scale {scale:.2f})')
+  assert e_ref <= 3e-3 * scale + 1e-5
+  assert e_emu <= 1.2e-3 * scale + 1e-5          # one fp16 ulp of the largest outputs: summation order only
+
+
 @pytest.mark.parametrize('C,HW,sizes', [(512, 20, (8, 32, 50, 70, 63)), (256, 40, (4, 12, 63, 20, 32)), (128, 40, (8, 40, 24, 63, 64))])
 def test_halo_kernel_output_does_not_depend_on_the_tile_size(fp, C, HW, sizes):
   """The 3x3 stride-1 kernel cuts what is less than a round of 512-pixel tiles into tiles of 1 .. 4 x 128 pixels, whichever finishes first
