@@ -81,10 +81,14 @@ def step_local(est, objects, world, rank):
   offs = [0]
   for a, b in sl:
     offs.append(offs[-1] + (b - a))
-  feats = est.scorer.extract_features_multi([dict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], mesh_tensors=est.mesh_tensors,
-                                                  mesh_diameter=est.diameter, ob_in_cams=refined[offs[o]:offs[o + 1]])
-                                             for o, ob in enumerate(objects)])
-  return torch.cat([pack_rows(feats[offs[o]:offs[o + 1]], refined[offs[o]:offs[o + 1]], shard) for o in range(len(objects))], 0)
+  # the all-gather records [feature 512 | pose 16] come straight from the library (no concatenation pass); only a rank whose shard is
+  # short (252 = 7 x 32 + 28) pads its block
+  rows = est.scorer.extract_rows_multi([dict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], mesh_tensors=est.mesh_tensors,
+                                             mesh_diameter=est.diameter, ob_in_cams=refined[offs[o]:offs[o + 1]])
+                                        for o, ob in enumerate(objects)])
+  if all(b - a == shard for a, b in sl):
+    return rows
+  return torch.cat([pack_rows(rows[offs[o]:offs[o + 1], :512], refined[offs[o]:offs[o + 1]], shard) for o in range(len(objects))], 0)
 
 
 def step_finalize(est, objects, world, rank, gathered, everywhere=False):
@@ -99,7 +103,12 @@ def step_finalize(est, objects, world, rank, gathered, everywhere=False):
     if not everywhere and o % world != rank:
       continue
     mine = gathered[0, o] if world == 1 else gathered[gather_order_index(o, world, gathered.device), o]
-    feats_all, poses_all = unpack_rows(mine.reshape(world * shard, -1), N_HYP, world)
+    mine = mine.reshape(world * shard, -1)
+    if world * shard == N_HYP:                   # every shard full: the tail reads the gathered rows in place, the poses are a view of them
+      logits, am = est.scorer.score_tail(mine, L=N_HYP)
+      results[o] = (am, mine[:, 512:].reshape(-1, 4, 4))
+      continue
+    feats_all, poses_all = unpack_rows(mine, N_HYP, world)
     logits, am = est.scorer.score_tail(feats_all, L=N_HYP)
     results[o] = (am, poses_all)
   return results
@@ -166,6 +175,13 @@ def tracking_fps(est, device, n_frames):
     rgbs.append(rgb)
     depths.append(dd)
   rgbs, depths = torch.cat(rgbs), torch.cat(depths)
+  # a frame as ONE buffer [depth float32 | rgb uint8] (what a capture thread would hand over): track_one then uploads it with one copy
+  nb_d, nb_c = 480 * 640 * 4, 480 * 640 * 3
+  packed = torch.empty((n_frames, nb_d + nb_c), dtype=torch.uint8, device=device)
+  packed[:, :nb_d] = depths.reshape(n_frames, -1).view(torch.uint8)
+  packed[:, nb_d:] = rgbs.reshape(n_frames, -1)
+  depths = [packed[f, :nb_d].view(torch.float).reshape(480, 640) for f in range(n_frames)]
+  rgbs = [packed[f, nb_d:].reshape(480, 640, 3) for f in range(n_frames)]
   out = {'frames': n_frames, 'sequence': 'seeded smooth SE(3) trajectory, <= 1 cm and <= 2 deg per frame, 480x640 RGB-D frames resident in HBM',
          'start_pose': 'every frame starts from the trajectory pose of the PREVIOUS frame (what a working tracker holds): the networks carry seeded '
                        'random weights, and a self-chained track walks 2 cm per frame away from the object - behind the camera after 30 frames, where '

@@ -33,6 +33,15 @@ class FpRenderOpts(Structure):
               ('has_light_color', c_int), ('light_color', c_float * 3), ('has_projection', c_int), ('projection', c_double * 16), ('d_rast', c_void_p)]
 
 
+class FpTrackArgs(Structure):
+  """fp_track_args (include/foundationpose_amd.h): one tracking frame, every launch of it."""
+  _fields_ = [('struct_size', ctypes.c_size_t), ('refine_net', c_void_p), ('score_net', c_void_p), ('mesh', c_void_p), ('d_rgb', c_void_p),
+              ('rgb_is_u8', c_int), ('d_depth', c_void_p), ('H', c_int), ('W', c_int), ('K', c_void_p), ('mesh_diameter', c_double),
+              ('refine_cfg', c_void_p), ('score_crop_ratio', c_double), ('score_normalize_xyz', c_int), ('iteration', c_int), ('n_hyp', c_int),
+              ('d_perturb', c_void_p), ('model_center', c_float * 3), ('d_pose', c_void_p), ('d_pose_of_mesh', c_void_p), ('d_poses', c_void_p),
+              ('d_scores', c_void_p), ('d_best', c_void_p), ('d_depth_f', c_void_p), ('d_xyz', c_void_p), ('d_rgb_f', c_void_p)]
+
+
 class FpObjectBatch(Structure):
   _fields_ = [('mesh', c_void_p), ('d_rgb', c_void_p), ('d_geom', c_void_p), ('H', c_int), ('W', c_int), ('K', c_void_p),
               ('mesh_diameter', c_double), ('n', c_int)]
@@ -70,6 +79,9 @@ _PROTOS = {
   'fp_net_tokens': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_score_features': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_score_tail': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_score_tail_scores': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+  'fp_score_predict_rows_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, c_double, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_track_frame': (c_int, [c_void_p, POINTER(FpTrackArgs), c_void_p]),
   'fp_pose_update': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_float, c_void_p, c_void_p]),
   'fp_pose_update_deepim': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p]),
   'fp_refine_predict': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, POINTER(FpRefineCfg), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -87,11 +87,14 @@ extern "C" int fp_ctx_create(int device, fp_ctx **out) {
   fp_ctx *c = new fp_ctx;
   c->device = device;
   c->num_cu = prop.multiProcessorCount;
-  if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+  // one allocation: the 4-KB zero page, then the score tail's arrival counters (zeros as well)
+  if (hipMalloc(&c->zero_page, 4096 + FP_TAIL_MAX_GROUPS * sizeof(int)) != hipSuccess ||
+      hipMemset(c->zero_page, 0, 4096 + FP_TAIL_MAX_GROUPS * sizeof(int)) != hipSuccess) {
     delete c;
     fp_set_error("fp_ctx_create: zero page allocation failed");
     return FP_ENOMEM;
   }
+  c->tail_counter = (int *)((char *)c->zero_page + 4096);
   const int rc = fp_set_kernel_attributes(c);      // per device: every kernel of the library that needs more than 64 KB of LDS
   if (rc != FP_OK) {
     (void)hipFree(c->zero_page);
@@ -555,8 +558,14 @@ static int count_runs(const fp_object_batch *objs, int n_obj) {
   return k;
 }
 
-extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
-                                       float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream) {
+// `centered` (optional, one run of like objects): poses @ get_tf_to_centered_mesh() of the LAST iteration, written by that pass' tail launch
+struct RefineFinal {
+  float *centered;
+  float cneg[3];
+};
+
+static int refine_predict_impl(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
+                               float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream, const RefineFinal *fin) {
   FP_REQUIRE(ctx && net && cfg && d_poses, "fp_refine_predict_multi: null argument");
   FP_REQUIRE(iteration >= 0, "fp_refine_predict_multi: bad iteration");
   int N = 0;
@@ -637,9 +646,14 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
         t.tf = tf, t.bbox = bbox;
         t.next_window = it + 1 < iteration;
         t.win = crop_window_k(ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160);
+        if (fin && it + 1 == iteration) {
+          t.centered = fin->centered;
+          for (int c = 0; c < 3; ++c) t.cneg[c] = fin->cneg[c];
+        }
         FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get(), &t));
         continue;
       }
+      FP_REQUIRE(!fin, "refine pass: the centred poses come from the fused tail launch (one run of like objects, FP_TAIL_SPLIT unset)");
       FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get()));     // ONE network pass for every object (joins `ab`)
       // pose update: one launch per run of objects with the same translation scale (one launch when they share a mesh)
       off = 0;
@@ -664,6 +678,11 @@ extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_
   return rc;
 }
 
+extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
+                                       float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream) {
+  return refine_predict_impl(ctx, net, objs, n_obj, cfg, d_poses, iteration, d_trans, d_rot, stream, nullptr);
+}
+
 extern "C" int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_xyz_map,
                                  int H, int W, const double *K, double mesh_diameter, const fp_refine_cfg *cfg, float *d_poses, int N,
                                  int iteration, float *d_trans, float *d_rot, void *stream) {
@@ -672,8 +691,8 @@ extern "C" int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *
   return fp_refine_predict_multi(ctx, net, &ob, 1, cfg, d_poses, iteration, d_trans, d_rot, stream);
 }
 
-extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, double crop_ratio,
-                                               int normalize_xyz, const float *d_poses, float *d_feats, void *stream) {
+static int score_features_impl(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, double crop_ratio,
+                               int normalize_xyz, const float *d_poses, float *d_feats, int feat_ld, bool with_pose, void *stream) {
   FP_REQUIRE(ctx && net && d_poses && d_feats, "fp_score_predict_features_multi: null argument");
   int N = 0;
   FP_TRY(check_objs(objs, n_obj, &N));
@@ -724,12 +743,22 @@ extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, c
       o = e;
     }
     FP_TRY(fo.join());
-    FP_TRY(fp_score_features_ab(ctx, net, net_in, N, d_feats, s, ab.get()));
+    FP_TRY(fp_score_features_ab(ctx, net, net_in, N, d_feats, s, ab.get(), feat_ld, with_pose ? d_poses : nullptr));
     return FP_OK;
   };
   int rc = body();
   ctx->arena.off = mark;
   return rc;
+}
+
+extern "C" int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, double crop_ratio,
+                                               int normalize_xyz, const float *d_poses, float *d_feats, void *stream) {
+  return score_features_impl(ctx, net, objs, n_obj, crop_ratio, normalize_xyz, d_poses, d_feats, 512, false, stream);
+}
+
+extern "C" int fp_score_predict_rows_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, double crop_ratio,
+                                           int normalize_xyz, const float *d_poses, float *d_rows, void *stream) {
+  return score_features_impl(ctx, net, objs, n_obj, crop_ratio, normalize_xyz, d_poses, d_rows, 528, true, stream);
 }
 
 extern "C" int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_depth,
@@ -738,6 +767,74 @@ extern "C" int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const f
   FP_REQUIRE(N >= 0, "fp_score_predict_features: N<0");
   fp_object_batch ob = {mesh, d_rgb, d_depth, H, W, K, mesh_diameter, N};
   return fp_score_predict_features_multi(ctx, net, &ob, 1, crop_ratio, normalize_xyz, d_poses, d_feats, stream);
+}
+
+// ---- one tracking frame, every launch of it (src/estimater.py:250-268; n_hyp > 1: the multi-hypothesis mode of BASELINE configs[4]) ----
+// hypotheses of the multi-hypothesis mode: R_i = dR_i R, t_i = t + dt_i (tracking.py), hypothesis 0 = the pose itself
+__global__ void track_hypotheses_kernel(const float *__restrict__ P, const float *__restrict__ pose, int n, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float *p = P + (size_t)i * 16;
+  float *o = out + (size_t)i * 16;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      float acc = __fmul_rn(p[r * 4 + 0], pose[0 * 4 + c]);
+      acc = __fadd_rn(acc, __fmul_rn(p[r * 4 + 1], pose[1 * 4 + c]));
+      acc = __fadd_rn(acc, __fmul_rn(p[r * 4 + 2], pose[2 * 4 + c]));
+      o[r * 4 + c] = acc;
+    }
+    o[r * 4 + 3] = __fadd_rn(pose[r * 4 + 3], p[r * 4 + 3]);
+  }
+  o[12] = 0.f, o[13] = 0.f, o[14] = 0.f, o[15] = 1.f;
+}
+
+extern "C" int fp_track_frame(fp_ctx *ctx, const fp_track_args *a, void *stream) {
+  FP_REQUIRE(ctx && a, "fp_track_frame: null argument");
+  FP_REQUIRE(a->struct_size == sizeof(fp_track_args), "fp_track_frame: fp_track_args.struct_size = %zu (this library knows %zu)", a->struct_size, sizeof(fp_track_args));
+  FP_REQUIRE(a->refine_net && a->mesh && a->d_rgb && a->d_depth && a->K && a->refine_cfg && a->d_pose && a->d_pose_of_mesh && a->d_depth_f && a->d_xyz,
+             "fp_track_frame: null field");
+  FP_REQUIRE(a->H > 0 && a->W > 0 && a->iteration >= 1 && a->n_hyp >= 1, "fp_track_frame: bad H / W / iteration / n_hyp");
+  FP_REQUIRE(!a->rgb_is_u8 || a->d_rgb_f, "fp_track_frame: a uint8 frame needs the float workspace d_rgb_f");
+  const bool multi = a->n_hyp > 1;
+  FP_REQUIRE(!multi || (a->score_net && a->d_perturb && a->d_poses && a->d_scores && a->d_best), "fp_track_frame: n_hyp > 1 needs score_net, d_perturb, d_poses, d_scores, d_best");
+  hipStream_t s = (hipStream_t)stream;
+  // depth prelude: erode -> bilateral -> back-projection with the float32 camera matrix (src/estimater.py:256-260), + uint8 -> float colours
+  double K32[9];
+  for (int i = 0; i < 9; ++i) K32[i] = (double)(float)a->K[i];
+  FP_TRY(launch_depth_prefilter(a->d_depth, a->H, a->W, 0.001f, 0.8f, 100.f, 100.f, 2.f, 100000.f, K32, 3.0e38f, a->d_depth_f, a->d_xyz,
+                                a->rgb_is_u8 ? (const uint8_t *)a->d_rgb : nullptr, a->rgb_is_u8 ? a->d_rgb_f : nullptr, s));
+  const float *rgb_f = a->rgb_is_u8 ? a->d_rgb_f : (const float *)a->d_rgb;
+  RefineFinal fin;
+  for (int c = 0; c < 3; ++c) fin.cneg[c] = -a->model_center[c];
+  if (!multi) {
+    // track_one: the pose is refined IN PLACE; its last tail launch also writes pose @ get_tf_to_centered_mesh()
+    fin.centered = a->d_pose_of_mesh;
+    fp_object_batch ob = {a->mesh, rgb_f, a->d_xyz, a->H, a->W, a->K, a->mesh_diameter, 1};
+    return refine_predict_impl(ctx, a->refine_net, &ob, 1, a->refine_cfg, a->d_pose, a->iteration, nullptr, nullptr, stream, &fin);
+  }
+  hipLaunchKernelGGL(track_hypotheses_kernel, dim3((a->n_hyp + 63) / 64), dim3(64), 0, s, a->d_perturb, a->d_pose, a->n_hyp, a->d_poses);
+  FP_CHECK_HIP(hipGetLastError());
+  fp_object_batch ob = {a->mesh, rgb_f, a->d_xyz, a->H, a->W, a->K, a->mesh_diameter, a->n_hyp};
+  FP_TRY(refine_predict_impl(ctx, a->refine_net, &ob, 1, a->refine_cfg, a->d_poses, a->iteration, nullptr, nullptr, stream, nullptr));
+  FP_TRY(fp_arena_ensure(ctx, (size_t)a->n_hyp * (512 + 1) * 4 + 4096));
+  const size_t mark = ctx->arena.off;
+  float *feats = (float *)ctx->arena.take((size_t)a->n_hyp * 512 * sizeof(float));
+  float *logits = (float *)ctx->arena.take((size_t)a->n_hyp * sizeof(float));
+  int rc = (feats && logits) ? FP_OK : FP_ENOMEM;
+  if (rc != FP_OK) fp_set_error("fp_track_frame: arena exhausted");
+  if (rc == FP_OK) {
+    fp_object_batch od = {a->mesh, rgb_f, a->d_depth_f, a->H, a->W, a->K, a->mesh_diameter, a->n_hyp};
+    rc = fp_score_predict_features_multi(ctx, a->score_net, &od, 1, a->score_crop_ratio, a->score_normalize_xyz, a->d_poses, feats, stream);
+  }
+  if (rc == FP_OK) {
+    ScoreTailOut o;
+    o.logits = logits, o.scores = a->d_scores, o.score_offset = 100.f, o.argmax = a->d_best;
+    o.poses = a->d_poses, o.best_pose = a->d_pose, o.best_centered = a->d_pose_of_mesh;
+    for (int c = 0; c < 3; ++c) o.cneg[c] = fin.cneg[c];
+    rc = fp_score_tail_impl(ctx, a->score_net, feats, 512, 1, a->n_hyp, o, s);
+  }
+  ctx->arena.off = mark;
+  return rc;
 }
 
 int conv_ksplit(const ConvArgs &a, int num_cu);      // conv.hip

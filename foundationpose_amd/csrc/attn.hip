@@ -481,6 +481,7 @@ __global__ __launch_bounds__(512) void refine_tail_kernel(RefineTailArgs a) {
   for (int i = 0; i < 9; ++i) dp.K[i] = a.K[i];
   pose_update_one(b, a.poses, delta[0], delta[1], a.rot_dim, a.trans_tanh, a.tn0, a.tn1, a.tn2, a.rot_normalizer, a.trans_scale, dp, a.poses);
   if (a.next_window) crop_window_tf_one(b, a.poses, a.win, a.tf, a.bbox);
+  if (a.centered) pose_of_mesh_one(a.poses + (size_t)b * 16, a.cneg, a.centered + (size_t)b * 16);
 }
 
 int launch_refine_tail(const RefineTailArgs &a, int N, hipStream_t s) {
@@ -497,213 +498,6 @@ int launch_mean_head(const float *partial, int nparts, const float *g, const flo
   FP_REQUIRE(nparts >= 1 && nparts <= MH_MAXPARTS, "mean_head: %d partial rows per hypothesis (at most %d)", nparts, MH_MAXPARTS);
   if (Bn == 0) return FP_OK;
   hipLaunchKernelGGL(mean_head_kernel, dim3(Bn), dim3(512), 0, s, partial, nparts, g, b, T, hw, hb, out_dim, out);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-// mean over tokens of an fp16 (Bn*T, 512) tensor -> fp32 (Bn, 512)   (score_network.py:74)
-__global__ __launch_bounds__(256) void token_mean_kernel(const f16 *__restrict__ x, int T, float *__restrict__ out) {
-  __shared__ float part[4][512];
-  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int t = wave; t < T; t += 4) {
-    half8 v = *reinterpret_cast<const half8 *>(x + ((size_t)b * T + t) * 512 + lane * 8);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) part[wave][lane * 8 + i] = acc[i];
-  __syncthreads();
-  for (int f = threadIdx.x; f < 512; f += 256)
-    out[(size_t)b * 512 + f] = ((part[0][f] + part[1][f]) + (part[2][f] + part[3][f])) * (1.f / (float)T);
-}
-
-int launch_token_mean(const f16 *x, int Bn, int T, float *out, hipStream_t s) {
-  if (Bn == 0) return FP_OK;
-  hipLaunchKernelGGL(token_mean_kernel, dim3(Bn), dim3(256), 0, s, x, T, out);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-// y[m][n] = sum_k x[m][k] w[n][k] + b[n], fp32 in / out, one wave per output element group (tiny matrices:
-// the per-object score tail, 0.66 GFLOP per 252 hypotheses).
-__global__ __launch_bounds__(256) void small_linear_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                           const float *__restrict__ bias, int M, int K, int N,
-                                                           float *__restrict__ out) {
-  const int m = blockIdx.y;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const float *xr = x + (size_t)m * K, *wr = w + (size_t)n * K;
-  // float64 accumulation: these layers form the cross-hypothesis score tail, whose logits differ between hypotheses by 1e-4 ..
-  // 1e-3 on top of O(1) common parts - fp32 summation noise (4e-6) would be a visible part of that; the work is negligible
-  double s = 0.0;
-  for (int k = lane * 4; k < K; k += 256) {
-    const float4 a = *reinterpret_cast<const float4 *>(xr + k);
-    const float4 c = *reinterpret_cast<const float4 *>(wr + k);
-    s += (double)a.x * c.x + (double)a.y * c.y + (double)a.z * c.z + (double)a.w * c.w;
-  }
-  s = wave_sum_d(s);
-  if (lane == 0) out[(size_t)m * N + n] = (float)(s + (bias ? (double)bias[n] : 0.0));
-}
-
-// The same for N >= 64 columns: one LANE per output column (weights transposed (K, N): lanes read consecutive columns of a row,
-// coalesced), 4 rows of x per workgroup staged in LDS and read as broadcasts - 512 float64 FMAs per output and NO cross-lane
-// reduction (the wave-per-output form spends most of its instructions on 64-lane double reductions, in ~10^5 workgroups).
-#define SLT_ROWS 4
-__global__ __launch_bounds__(256) void small_linear_t_kernel(const float *__restrict__ x, const float *__restrict__ wt,
-                                                             const float *__restrict__ bias, int M, int K, int N, float *__restrict__ out) {
-  __shared__ float xs[SLT_ROWS][1024];
-  const int m0 = blockIdx.y * SLT_ROWS, n = blockIdx.x * 256 + threadIdx.x;
-  for (int i = threadIdx.x; i < SLT_ROWS * K; i += 256) {
-    const int r = i / K, k = i - r * K;
-    xs[r][k] = x[(size_t)min(m0 + r, M - 1) * K + k];
-  }
-  __syncthreads();
-  if (n >= N) return;
-  double acc[SLT_ROWS];
-#pragma unroll
-  for (int r = 0; r < SLT_ROWS; ++r) acc[r] = 0.0;
-  for (int k0 = 0; k0 < K; k0 += 8) {
-    float wv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) wv[u] = wt[(size_t)(k0 + u) * N + n];
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-      for (int r = 0; r < SLT_ROWS; ++r) acc[r] += (double)xs[r][k0 + u] * (double)wv[u];
-  }
-  const double b = bias ? (double)bias[n] : 0.0;
-#pragma unroll
-  for (int r = 0; r < SLT_ROWS; ++r)
-    if (m0 + r < M) out[(size_t)(m0 + r) * N + n] = (float)(acc[r] + b);
-}
-
-int launch_small_linear(const float *x, const float *w, const float *wt, const float *b, int M, int K, int N, float *out, hipStream_t s) {
-  FP_REQUIRE(K % 8 == 0 && K <= 1024, "small_linear: K=%d must be a multiple of 8, <= 1024", K);
-  if (M == 0 || N == 0) return FP_OK;
-  if (wt && N >= 64) hipLaunchKernelGGL(small_linear_t_kernel, dim3((N + 255) / 256, (M + SLT_ROWS - 1) / SLT_ROWS), dim3(256), 0, s, x, wt, b, M, K, N, out);
-  else hipLaunchKernelGGL(small_linear_kernel, dim3((N + 3) / 4, M), dim3(256), 0, s, x, w, b, M, K, N, out);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-// Cross-hypothesis self-attention (score_network.py:83): qkv (groups*L, 1536) fp32 -> out (groups*L, 512).
-// One workgroup per (query, group); 4 waves = 4 heads; scores held in LDS (L <= 4096).
-#define CA_MAXL 2048
-__global__ __launch_bounds__(256) void cross_attention_kernel(const float *__restrict__ qkv, int L, float *__restrict__ out) {
-  // float64 scores / softmax / weighted sum (see small_linear_kernel): with the q/k gain of the seeded scorer the scores are
-  // O(100) with hypothesis-specific parts of O(1); in fp32 their rounding alone moves the logits by several 1e-6
-  __shared__ double sc[4][CA_MAXL];
-  __shared__ double qs[4][128];
-  const int i = blockIdx.x, grp = blockIdx.y, hd = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float *base = qkv + (size_t)grp * L * 1536;
-  const float *qr = base + (size_t)i * 1536 + hd * 128;
-  qs[hd][lane * 2] = qr[lane * 2];
-  qs[hd][lane * 2 + 1] = qr[lane * 2 + 1];
-  __syncthreads();
-  const double scale = 0.08838834764831845;
-  double mx = -1.0e300;
-  // scores: a lane owns keys lane, lane + 64, ... and adds the 128 products of each in index order itself (a wave-wide reduction per
-  // key - 12 cross-lane double adds for 2 products per lane - was most of this kernel: 104 -> 73 us at L = 252); four keys in flight per lane
-  for (int j0 = lane; j0 < L; j0 += 256) {
-    const float4 *kr[4];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int u = 0; u < 4; ++u) kr[u] = reinterpret_cast<const float4 *>(base + (size_t)min(j0 + 64 * u, L - 1) * 1536 + 512 + hd * 128);
-#pragma unroll 4                                   // (fully unrolled, hipcc held 128 float4 loads live: 512 VGPRs and 87 spilled)
-    for (int d4 = 0; d4 < 32; ++d4) {
-      float4 kv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) kv[u] = kr[u][d4];
-      const double qa = qs[hd][4 * d4], qb = qs[hd][4 * d4 + 1], qc = qs[hd][4 * d4 + 2], qd = qs[hd][4 * d4 + 3];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc[u] += qa * (double)kv[u].x;
-        acc[u] += qb * (double)kv[u].y;
-        acc[u] += qc * (double)kv[u].z;
-        acc[u] += qd * (double)kv[u].w;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (j0 + 64 * u < L) {
-        const double sv = acc[u] * scale;
-        sc[hd][j0 + 64 * u] = sv;
-        mx = fmax(mx, sv);
-      }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-  __builtin_amdgcn_s_waitcnt(0);
-  __syncthreads();
-  double sum = 0.0;
-  for (int j = lane; j < L; j += 64) {
-    const double e = exp(sc[hd][j] - mx);
-    sc[hd][j] = e;
-    sum += e;
-  }
-  sum = wave_sum_d(sum);
-  __syncthreads();
-  double o0 = 0.0, o1 = 0.0;
-  for (int j0 = 0; j0 < L; j0 += 8) {
-    float2 vv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const float2 *>(base + (size_t)min(j0 + u, L - 1) * 1536 + 1024 + hd * 128 + lane * 2);
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (j0 + u < L) {
-        const double pj = sc[hd][j0 + u];
-        o0 += pj * (double)vv[u].x;
-        o1 += pj * (double)vv[u].y;
-      }
-  }
-  const double inv = 1.0 / sum;
-  float *orow = out + ((size_t)grp * L + i) * 512 + hd * 128;
-  orow[lane * 2] = (float)(o0 * inv);
-  orow[lane * 2 + 1] = (float)(o1 * inv);
-}
-
-int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s) {
-  FP_REQUIRE(L >= 1 && L <= CA_MAXL, "score tail: L=%d must be in [1,%d]", L, CA_MAXL);
-  if (groups == 0) return FP_OK;
-  hipLaunchKernelGGL(cross_attention_kernel, dim3(L, groups), dim3(256), 0, s, qkv, L, out);
-  FP_CHECK_HIP(hipGetLastError());
-  return FP_OK;
-}
-
-// per-group argmax, first maximum wins (torch.argmax tie rule on a 1-D tensor)
-__global__ __launch_bounds__(64) void argmax_kernel(const float *__restrict__ logits, int L, int32_t *__restrict__ out) {
-  const int grp = blockIdx.x, lane = threadIdx.x;
-  float best = -3.0e38f;
-  int bi = 0x7fffffff;
-  for (int j = lane; j < L; j += 64) {
-    float v = logits[(size_t)grp * L + j];
-    if (v > best || (v == best && j < bi)) {
-      best = v;
-      bi = j;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float ob = __shfl_xor(best, o);
-    int oi = __shfl_xor(bi, o);
-    if (ob > best || (ob == best && oi < bi)) {
-      best = ob;
-      bi = oi;
-    }
-  }
-  if (lane == 0) out[grp] = bi;
-}
-
-int launch_argmax(const float *logits, int groups, int L, int32_t *out, hipStream_t s) {
-  if (groups == 0) return FP_OK;
-  hipLaunchKernelGGL(argmax_kernel, dim3(groups), dim3(64), 0, s, logits, L, out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

@@ -89,6 +89,7 @@ struct fp_ctx {
   hipEvent_t ev_ref = nullptr;       // time origin of the launch spans, recorded when profiling is switched on
   int num_cu = 256;
   void *zero_page = nullptr;   // 4 KB of zeros: DMA source for out-of-image taps
+  int *tail_counter = nullptr; // FP_TAIL_MAX_GROUPS zeros: arrival counters of the score tail's last launch (left at zero by every call)
   // side streams for the per-object stages (crop window, render, observed crop) of a multi-object pass: with 8 objects
   // x 32 hypotheses a render launch fills a quarter of the chip, so the objects' stages run side by side and join the
   // launch stream before the (single) network pass
@@ -162,7 +163,8 @@ int fp_hyp_chunk(int n_total);             // hypotheses per network pass (FP_CH
 // and the next crop windows as ONE launch behind the join of the heads (refine_tail_kernel) instead of two mean_head launches here
 int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab,
                          RefineTailArgs *tail = nullptr);
-int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, hipStream_t s, StreamFanout *ab);
+int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, hipStream_t s, StreamFanout *ab, int feat_ld = 512,
+                         const float *d_poses = nullptr);      // feat_ld / d_poses: [feature | pose] rows of the all-gather (score_tail.hip)
 
 // profiling hooks (events on the launch stream)
 struct ProfScope {
@@ -310,10 +312,23 @@ int launch_head_mlp(fp_ctx *ctx, const HeadMlpArgs &a, hipStream_t s);
 // Sum of `nparts` consecutive partial rows per hypothesis (fixed order) / T, gamma, beta, Linear(512 -> out_dim)
 int launch_mean_head(const float *partial, int nparts, const float *g, const float *b, int Bn, int T, const float *hw, const float *hb,
                      int out_dim, float *out, hipStream_t s);
-int launch_token_mean(const f16 *x, int Bn, int T, float *out, hipStream_t s);
-int launch_small_linear(const float *x, const float *w, const float *wt, const float *b, int M, int K, int N, float *out, hipStream_t s);
-int launch_cross_attention(const float *qkv, int groups, int L, float *out, hipStream_t s);
-int launch_argmax(const float *logits, int groups, int L, int32_t *out, hipStream_t s);
+// score_tail.hip: token mean + att.out_proj of ScoreNet in one launch; att_cross + linear + argmax in two
+int launch_score_feat(const f16 *att, int Bn, int T, const float *wt, const float *bias, float *out, int ld, const float *poses, hipStream_t s);
+struct ScoreTailOut {
+  float *logits = nullptr;             // (groups, L), required
+  int32_t *argmax = nullptr;           // (groups), optional
+  float *scores = nullptr;             // (groups, L) = logits + score_offset, optional (ScorePredictor.predict: + 100, predict_score.py:209)
+  float score_offset = 0.f;
+  // optional, with argmax (tracking): the winning hypothesis' pose (group g: poses + g L 16) -> best_pose (groups, 16) and
+  // best_pose @ get_tf_to_centered_mesh() -> best_centered (groups, 16)
+  const float *poses = nullptr;
+  float *best_pose = nullptr, *best_centered = nullptr;
+  float cneg[3] = {0.f, 0.f, 0.f};
+};
+int launch_score_tail(const float *feats, int feat_ld, const float *wqk_t, const float *bqk, const double *u, const double *c, double b_eff, int groups, int L,
+                      float *qk, double *sv, int *counter, const ScoreTailOut &o, hipStream_t s);
+#define FP_TAIL_MAX_GROUPS 4096
+int fp_score_tail_impl(fp_ctx *ctx, const fp_net *net, const float *d_feats, int feat_ld, int groups, int L, const ScoreTailOut &o, hipStream_t s);      // net.hip
 // trans_tanh: 0 raw, 1 tanh * trans_normalizer, 2 trans_rep='deepim' (needs tf N x 9, K, resize = input_resize[0])
 // The tail of a refinement pass as one launch (attn.hip: refine_tail_kernel): both heads' token mean + output Linear, the pose update in
 // place and, with `next_window`, the crop windows of the next iteration (tf / bbox overwritten; the deepim branch reads tf first)
@@ -332,6 +347,10 @@ struct RefineTailArgs {
   float *tf, *bbox;              // (N,9), (N,4)
   int next_window;
   CropWindowK win;
+  // optional (the last pass of a tracking frame): pose @ get_tf_to_centered_mesh() of every hypothesis, (N,4,4) - src/estimater.py:268;
+  // cneg = -model_center (the translation column of that matrix)
+  float *centered = nullptr;
+  float cneg[3] = {0.f, 0.f, 0.f};
 };
 int launch_refine_tail(const RefineTailArgs &a, int N, hipStream_t s);
 int launch_pose_update(const float *poseA, const float *trans, const float *rot, int N, int rot_dim, int trans_tanh,

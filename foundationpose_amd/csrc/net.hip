@@ -38,7 +38,11 @@ struct fp_net {
   float *pe = nullptr;  // 400 x 512
   HeadW heads[2];       // refine: trans, rot
   LinP att_q, att_k, att_v;  // score: self.att in_proj on tokens
-  LinF32 att_out, cross_in, cross_out, lin;
+  LinF32 att_out;
+  // score tail (score_tail.hip): q | k of att_cross transposed (512, 1024) fp32 + bias (1024); the value path folded in float64 at load
+  // time: u (4, 512), c (4), b_eff
+  float *tail_wqk_t = nullptr, *tail_bqk = nullptr;
+  double *tail_u = nullptr, *tail_c = nullptr, tail_b_eff = 0.0;
   std::vector<void *> allocs;
 };
 
@@ -211,6 +215,43 @@ int make_linf32(fp_net *net, const SD &sd, const std::string &wkey, const std::s
   return upload(net, tr, &out->wt);
 }
 
+// att_cross + linear (score_network.py:83-85) for score_tail.hip: q | k rows of in_proj transposed; the value path folded in float64:
+//   w_eff = W_o^T lin.w, b_eff = lin.w . b_o + lin.b, u_h = Wv_h^T w_eff^h, c_h = bv_h . w_eff^h   (derivation: score_tail.hip)
+int make_score_tail(fp_net *net, const SD &sd) {
+  const fp_tensor *wi, *bi, *wo, *bo, *lw, *lb;
+  FP_TRY(need(sd, "att_cross.in_proj_weight", 2, {1536, 512}, &wi));
+  FP_TRY(need(sd, "att_cross.in_proj_bias", 1, {1536}, &bi));
+  FP_TRY(need(sd, "att_cross.out_proj.weight", 2, {512, 512}, &wo));
+  FP_TRY(need(sd, "att_cross.out_proj.bias", 1, {512}, &bo));
+  FP_TRY(need(sd, "linear.weight", 2, {1, 512}, &lw));
+  FP_TRY(need(sd, "linear.bias", 1, {1}, &lb));
+  std::vector<float> wt((size_t)512 * 1024), bqk(1024);
+  for (int n = 0; n < 1024; ++n) {
+    bqk[n] = bi->data[n];
+    for (int k = 0; k < 512; ++k) wt[(size_t)k * 1024 + n] = wi->data[(size_t)n * 512 + k];
+  }
+  std::vector<double> weff(512, 0.0), u((size_t)4 * 512, 0.0), c(4, 0.0);
+  double beff = (double)lb->data[0];
+  for (int n = 0; n < 512; ++n) {
+    const double l = (double)lw->data[n];
+    beff += l * (double)bo->data[n];
+    for (int k = 0; k < 512; ++k) weff[k] += l * (double)wo->data[(size_t)n * 512 + k];
+  }
+  for (int h = 0; h < 4; ++h)
+    for (int d = 0; d < 128; ++d) {
+      const double w = weff[h * 128 + d];
+      const float *vr = wi->data + (size_t)(1024 + h * 128 + d) * 512;
+      c[h] += w * (double)bi->data[1024 + h * 128 + d];
+      for (int k = 0; k < 512; ++k) u[(size_t)h * 512 + k] += w * (double)vr[k];
+    }
+  net->tail_b_eff = beff;
+  FP_TRY(upload(net, wt, &net->tail_wqk_t));
+  FP_TRY(upload(net, bqk, &net->tail_bqk));
+  FP_TRY(upload(net, u, &net->tail_u));
+  FP_TRY(upload(net, c, &net->tail_c));
+  return FP_OK;
+}
+
 int make_trunk(fp_net *net, const SD &sd, const std::string &eA, const std::string &eAB, bool bn) {
   auto cbr = [&](const std::string &pre, int stride, ConvW *o) { return make_conv(net, sd, pre + ".net.0", pre + ".net.1", bn, stride, o); };
   auto res = [&](const std::string &pre, ConvW *o1, ConvW *o2) {
@@ -275,9 +316,7 @@ extern "C" int fp_net_create(fp_ctx *ctx, int kind, const fp_tensor *tensors, in
       FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 512, &net->att_k));
       FP_TRY(make_linear(net.get(), sd, "att.in_proj_weight", "att.in_proj_bias", 1024, &net->att_v));
       FP_TRY(make_linf32(net.get(), sd, "att.out_proj.weight", "att.out_proj.bias", 512, 512, &net->att_out));
-      FP_TRY(make_linf32(net.get(), sd, "att_cross.in_proj_weight", "att_cross.in_proj_bias", 1536, 512, &net->cross_in));
-      FP_TRY(make_linf32(net.get(), sd, "att_cross.out_proj.weight", "att_cross.out_proj.bias", 512, 512, &net->cross_out));
-      FP_TRY(make_linf32(net.get(), sd, "linear.weight", "linear.bias", 1, 512, &net->lin));
+      FP_TRY(make_score_tail(net.get(), sd));
     }
     return FP_OK;
   };
@@ -687,7 +726,8 @@ extern "C" int fp_score_features(fp_ctx *ctx, const fp_net *net, const void *d_n
   return fp_score_features_ab(ctx, net, d_net_in, N, d_feats, (hipStream_t)stream, nullptr);
 }
 
-int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, hipStream_t s, StreamFanout *ab) {
+int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, hipStream_t s, StreamFanout *ab, int feat_ld,
+                         const float *d_poses) {
   FP_REQUIRE(ctx && net && d_net_in && d_feats, "fp_score_features: null argument");
   FP_REQUIRE(net->kind == FP_NET_SCORE, "fp_score_features: not a ScoreNetMultiPair");
   FP_REQUIRE(N >= 0, "fp_score_features: N<0");
@@ -704,15 +744,13 @@ int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, i
     TAKE(qk, f16, (size_t)M * 1024);
     TAKE(vt, f16, (size_t)N * 4 * 128 * 416);
     TAKE(att, f16, (size_t)M * 512);
-    TAKE(mean, float, (size_t)N * 512);
     const LinP *q_[1] = {&net->att_q}, *k_[1] = {&net->att_k}, *v_[1] = {&net->att_v};
     f16 *qk_[1] = {qk}, *vt_[1] = {vt};
     ProfScope wall(ctx, s, "heads_wall", 0.0);
     FP_TRY(run_qkv(ctx, q_, k_, v_, 1, tok, N, qk_, vt_, s));
     FP_TRY(launch_attention(ctx, qk, vt, N, 400, att, s));
-    // mean over tokens commutes with out_proj (score_network.py:73-74)
-    FP_TRY(launch_token_mean(att, N, 400, mean, s));
-    FP_TRY(launch_small_linear(mean, net->att_out.w, net->att_out.wt, net->att_out.b, N, 512, 512, d_feats + (size_t)s0 * 512, s));
+    // mean over tokens commutes with out_proj (score_network.py:73-74): both in one launch
+    FP_TRY(launch_score_feat(att, N, 400, net->att_out.wt, net->att_out.b, d_feats + (size_t)s0 * feat_ld, feat_ld, d_poses ? d_poses + (size_t)s0 * 16 : nullptr, s));
     return FP_OK;
   };
   int rc = FP_OK;
@@ -725,28 +763,40 @@ int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, i
   return rc;
 }
 
-extern "C" int fp_score_tail(fp_ctx *ctx, const fp_net *net, const float *d_feats, int groups, int L, float *d_logits,
-                             int32_t *d_argmax, void *stream) {
-  FP_REQUIRE(ctx && net && d_feats && d_logits, "fp_score_tail: null argument");
+int fp_score_tail_impl(fp_ctx *ctx, const fp_net *net, const float *d_feats, int feat_ld, int groups, int L, const ScoreTailOut &o, hipStream_t s) {
+  FP_REQUIRE(ctx && net && d_feats && o.logits, "fp_score_tail: null argument");
   FP_REQUIRE(net->kind == FP_NET_SCORE, "fp_score_tail: not a ScoreNetMultiPair");
   FP_REQUIRE(groups >= 0 && L >= 1, "fp_score_tail: bad groups/L");
   if (groups == 0) return FP_OK;
-  hipStream_t s = (hipStream_t)stream;
   const int M = groups * L;
-  FP_TRY(fp_arena_ensure(ctx, (size_t)M * (1536 + 512 + 512) * 4 + (1 << 20)));
+  FP_REQUIRE(groups <= FP_TAIL_MAX_GROUPS, "fp_score_tail: %d groups (at most %d)", groups, FP_TAIL_MAX_GROUPS);
+  FP_TRY(fp_arena_ensure(ctx, (size_t)M * (1024 * 4 + 4 * 8) + (1 << 20)));
   const size_t mark = ctx->arena.off;
   auto body = [&]() -> int {
-    TAKE(qkv, float, (size_t)M * 1536);
-    TAKE(ca, float, (size_t)M * 512);
-    TAKE(co, float, (size_t)M * 512);
-    FP_TRY(launch_small_linear(d_feats, net->cross_in.w, net->cross_in.wt, net->cross_in.b, M, 512, 1536, qkv, s));
-    FP_TRY(launch_cross_attention(qkv, groups, L, ca, s));
-    FP_TRY(launch_small_linear(ca, net->cross_out.w, net->cross_out.wt, net->cross_out.b, M, 512, 512, co, s));
-    FP_TRY(launch_small_linear(co, net->lin.w, net->lin.wt, net->lin.b, M, 512, 1, d_logits, s));
-    if (d_argmax) FP_TRY(launch_argmax(d_logits, groups, L, d_argmax, s));
-    return FP_OK;
+    TAKE(qk, float, (size_t)M * 1024);
+    TAKE(sv, double, (size_t)M * 4);
+    // two launches: q | k rows + the folded value scalars; logits (+ scores, argmax, the winner's pose) - score_tail.hip
+    return launch_score_tail(d_feats, feat_ld, net->tail_wqk_t, net->tail_bqk, net->tail_u, net->tail_c, net->tail_b_eff, groups, L, qk, sv, ctx->tail_counter, o, s);
   };
   int rc = body();
   ctx->arena.off = mark;
   return rc;
+}
+
+extern "C" int fp_score_tail(fp_ctx *ctx, const fp_net *net, const float *d_feats, int groups, int L, float *d_logits,
+                             int32_t *d_argmax, void *stream) {
+  ScoreTailOut o;
+  o.logits = d_logits;
+  o.argmax = d_argmax;
+  return fp_score_tail_impl(ctx, net, d_feats, 512, groups, L, o, (hipStream_t)stream);
+}
+
+extern "C" int fp_score_tail_scores(fp_ctx *ctx, const fp_net *net, const float *d_feats, int feat_ld, int groups, int L, float score_offset,
+                                    float *d_logits, float *d_scores, int32_t *d_argmax, void *stream) {
+  ScoreTailOut o;
+  o.logits = d_logits;
+  o.argmax = d_argmax;
+  o.scores = d_scores;
+  o.score_offset = score_offset;
+  return fp_score_tail_impl(ctx, net, d_feats, feat_ld, groups, L, o, (hipStream_t)stream);
 }

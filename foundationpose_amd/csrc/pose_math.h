@@ -143,3 +143,14 @@ __device__ __forceinline__ void crop_window_tf_one(int b, const float *poses, co
     B[3] = __fadd_rn(__fmul_rn(i11, oh - 1.f), i12);
   }
 }
+
+// pose @ get_tf_to_centered_mesh() (src/estimater.py:82-86,268): that matrix is the identity with the translation column cneg = -model_center,
+// so the rotation block is copied and column 3 is row . (cneg, 1), summed left to right in float32.
+__device__ __forceinline__ void pose_of_mesh_one(const float *pose, const float *cneg, float *out) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float p0 = pose[i * 4 + 0], p1 = pose[i * 4 + 1], p2 = pose[i * 4 + 2], p3 = pose[i * 4 + 3];
+    out[i * 4 + 0] = p0, out[i * 4 + 1] = p1, out[i * 4 + 2] = p2;
+    out[i * 4 + 3] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p0, cneg[0]), __fmul_rn(p1, cneg[1])), __fmul_rn(p2, cneg[2])), p3);
+  }
+}

@@ -97,5 +97,5 @@ def sharded_refine_and_score(est, K, rgb, depth, xyz_map, poses, iteration, grou
     feats = torch.zeros((0, 512), dtype=torch.float32, device=poses.device)
   gathered = all_gather_rows(pack_rows(feats, refined, shard), group)
   feats_all, poses_all = unpack_rows(gathered, n, world)
-  logits, _ = est.scorer.score_tail(feats_all, L=n)      # replicated: 0.66 GFLOP, cheaper than a broadcast
-  return poses_all, logits.reshape(-1) + 100
+  _, _, scores = est.scorer.score_tail(feats_all, L=n, score_offset=100.0)      # replicated on every rank: cheaper than a broadcast
+  return poses_all, scores.reshape(-1)

@@ -8,6 +8,7 @@ rotation + guessed translation as float64, track before register -> RuntimeError
 the HIP library; with `dist_group` set the hypotheses are sharded over the ranks of one node
 (foundationpose_amd/dist.py) - the reference is single-GPU only.
 """
+import ctypes
 import logging
 import os
 
@@ -79,23 +80,14 @@ class FoundationPose:
     self.mesh_tensors = U.make_mesh_tensors(centred)
     sym = torch.eye(4)[None] if symmetry_tfs is None else torch.as_tensor(symmetry_tfs)
     self.symmetry_tfs = sym.to(device='cuda', dtype=torch.float)
-    # captured tracking graphs hold the addresses of the previous object's mesh and centring matrix: none survives a new object
-    self._graphs = {}
-    self._tf_centered_key = None
+    # tracking workspaces (and their captured graphs) hold the previous object's mesh handle and centre: none survives a new object
+    self._track_ws = {}
     logging.info("reset done")
 
   def get_tf_to_centered_mesh(self):
     tf = torch.eye(4, dtype=torch.float, device='cuda')
     tf[:3, 3] = -torch.as_tensor(self.model_center, device='cuda', dtype=torch.float)
     return tf
-
-  def _tf_to_centered_cached(self):
-    """get_tf_to_centered_mesh() built once per model centre (a tracking frame is ~1 ms: the three small launches that build the
-    matrix are worth keeping out of it)."""
-    key = np.asarray(self.model_center, dtype=np.float64).tobytes()
-    if getattr(self, '_tf_centered_key', None) != key:
-      self._tf_centered, self._tf_centered_key = self.get_tf_to_centered_mesh(), key
-    return self._tf_centered
 
   def to_device(self, s='cuda:0'):
     for name, value in list(vars(self).items()):
@@ -202,96 +194,152 @@ class FoundationPose:
     return (self.pose_last @ self.get_tf_to_centered_mesh()).data.cpu().numpy()
 
   # ------------------------------------------------------------------ tracking
-  def _track_frame(self, rgb, depth, K, pose_in, iteration, n_hyp, sigmas):
-    """Device work of one tracking frame, free of host synchronisation (so that it can be captured in a hipGraph): depth
-    filtering, back-projection, refinement of the previous pose (n_hyp == 1: src/estimater.py:256-266) or of n_hyp seeded
-    perturbations of it + scoring.  Returns (new pose (4,4), poses, scores, best_id, new pose @ get_tf_to_centered_mesh()) -
-    device tensors."""
-    from .tracking import tracking_hypotheses
-    # erode_depth -> bilateral_filter_depth -> depth2xyzmap_batch (src/estimater.py:256-260; the reference back-projects with the
-    # float32 camera matrix here), one launch; a uint8 frame's colours become float in the same launch
-    if rgb.dtype == torch.uint8 and rgb.is_contiguous() and tuple(rgb.shape) == tuple(depth.shape) + (3,):
-      depth, xyz_map, rgb = U.depth_prefilter(depth, K, radius=2, rgb_u8=rgb)
-    else:
-      rgb = rgb.to(torch.float)
-      depth, xyz_map = U.depth_prefilter(depth, K, radius=2)
-    shared = dict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K, glctx=self.glctx, mesh_diameter=self.diameter)
-    if n_hyp == 1:
-      pose, _ = self.refiner.predict(ob_in_cams=pose_in.reshape(-1, 4, 4), normal_map=None, xyz_map=xyz_map, iteration=iteration,
-                                     get_vis=False, **shared)
-      pose = pose.reshape(4, 4)
-      return pose, None, None, None, pose @ self._tf_to_centered_cached()
-    hyp = tracking_hypotheses(pose_in.reshape(4, 4), n_hyp, *sigmas)
-    refined, _ = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
-    scores, _ = self.scorer.predict(ob_in_cams=refined, normal_map=None, **shared)
-    best = scores.argmax()
-    pose = refined.index_select(0, best.reshape(1))[0]                             # (indexing by a 0-d tensor would synchronise)
-    return pose, refined, scores, best, pose @ self._tf_to_centered_cached()
-
   def enable_track_graph(self, on=True):
-    """Replay a tracking frame as ONE hipGraph: at 1 .. 64 hypotheses a frame is ~100 kernels of one workgroup round or less
+    """Replay a tracking frame as ONE hipGraph: at 1 .. 64 hypotheses a frame is ~80 kernels of one workgroup round or less
     each, so launch overhead and the gaps between launches are a large part of it.  The graph is captured at the first frame of a
     given (mode, frame size, camera, iteration count) and re-captured if the library's workspace is re-allocated."""
     self._graph_on = bool(on)
-    self._graphs = {}
+    for ws in getattr(self, '_track_ws', {}).values():
+      ws['graph'] = None
+
+  def _track_workspace(self, n_hyp, sigmas, iteration, shape, is_u8, K):
+    """Static device buffers of one tracking mode (every launch of a frame reads and writes fixed addresses, so the frame can be
+    replayed as a hipGraph): the frame itself - depth (float32) and colours behind one another in ONE buffer, so that a frame is one
+    host-to-device copy -, the library's workspace, the pose (refined in place from frame to frame) and the outputs."""
+    from . import _lib
+    from .tracking import perturbation_set
+    key = (n_hyp, sigmas, int(iteration), tuple(shape), bool(is_u8), np.asarray(K, dtype=np.float64).tobytes(), id(self.mesh_tensors['pos']),
+           np.asarray(self.model_center, dtype=np.float64).tobytes())
+    ws = self._track_ws.get(key) if hasattr(self, '_track_ws') else None
+    if ws is not None:
+      return ws
+    if not hasattr(self, '_track_ws'):
+      self._track_ws = {}
+    H, W = shape
+    dev = self.mesh_tensors['pos'].device
+    n_rgb = H * W * 3 * (1 if is_u8 else 4)
+    frame = torch.empty((H * W * 4 + n_rgb,), dtype=torch.uint8, device=dev)
+    ws = dict(frame=frame, depth=frame[:H * W * 4].view(torch.float).reshape(H, W),
+              rgb=(frame[H * W * 4:].reshape(H, W, 3) if is_u8 else frame[H * W * 4:].view(torch.float).reshape(H, W, 3)),
+              host=torch.empty((H * W * 4 + n_rgb,), dtype=torch.uint8).pin_memory(),
+              depth_f=torch.empty((H, W), dtype=torch.float, device=dev), xyz=torch.empty((H, W, 3), dtype=torch.float, device=dev),
+              rgb_f=torch.empty((H, W, 3), dtype=torch.float, device=dev) if is_u8 else None,
+              pose=torch.eye(4, dtype=torch.float, device=dev), pose_of_mesh=torch.eye(4, dtype=torch.float, device=dev),
+              Kd=np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3)), cfg=self.refiner._c_cfg(), holds_pose=None, graph=None)
+    a = _lib.FpTrackArgs()
+    a.struct_size = ctypes.sizeof(a)
+    a.refine_net, a.mesh = self.refiner.model.handle, _lib.device_mesh(self.refiner.ctx, self.mesh_tensors).handle
+    a.d_rgb, a.rgb_is_u8, a.d_depth, a.H, a.W = ws['rgb'].data_ptr(), 1 if is_u8 else 0, ws['depth'].data_ptr(), H, W
+    a.K, a.mesh_diameter = ws['Kd'].ctypes.data, float(self.diameter)
+    a.refine_cfg = ctypes.addressof(ws['cfg'])
+    a.iteration, a.n_hyp = int(iteration), int(n_hyp)
+    a.model_center[:] = [float(x) for x in np.asarray(self.model_center, dtype=np.float32)]
+    a.d_pose, a.d_pose_of_mesh = ws['pose'].data_ptr(), ws['pose_of_mesh'].data_ptr()
+    a.d_depth_f, a.d_xyz = ws['depth_f'].data_ptr(), ws['xyz'].data_ptr()
+    a.d_rgb_f = ws['rgb_f'].data_ptr() if is_u8 else None
+    if n_hyp > 1:
+      ws['perturb'] = torch.as_tensor(perturbation_set(int(n_hyp), *sigmas), device=dev).contiguous()
+      ws['poses'] = torch.empty((n_hyp, 4, 4), dtype=torch.float, device=dev)
+      ws['scores'] = torch.empty((n_hyp,), dtype=torch.float, device=dev)
+      ws['best'] = torch.zeros((1,), dtype=torch.int32, device=dev)
+      a.score_net = self.scorer.model.handle
+      a.score_crop_ratio, a.score_normalize_xyz = float(self.scorer.cfg['crop_ratio']), 1 if self.scorer.cfg['normalize_xyz'] else 0
+      a.d_perturb, a.d_poses, a.d_scores, a.d_best = ws['perturb'].data_ptr(), ws['poses'].data_ptr(), ws['scores'].data_ptr(), ws['best'].data_ptr()
+    ws['args'] = a
+    self._track_ws[key] = ws
+    return ws
 
   def _run_frame(self, rgb, depth, K, iteration, n_hyp, sigmas):
-    depth = torch.as_tensor(depth, device='cuda', dtype=torch.float)
-    rgb = torch.as_tensor(np.ascontiguousarray(rgb) if isinstance(rgb, np.ndarray) else rgb, device='cuda')
-    pose_in = self.pose_last.reshape(4, 4).to(torch.float)
-    if not getattr(self, '_graph_on', False):
-      return self._track_frame(rgb, depth, K, pose_in, iteration, n_hyp, sigmas)
+    """One tracking frame: upload (ONE copy), fp_track_frame (eager, or the replay of its captured hipGraph), the 4x4 result back.
+    Returns (pose_of_mesh as a HOST (4,4) float32 array - what track_one returns -, workspace).  Contract: `self.pose_last` and, in the
+    multi-hypothesis mode, `self.poses` / `self.scores` / `self.best_id` are VIEWS of the mode's static buffers, overwritten by the
+    next frame of the same mode; clone them to keep them."""
+    from . import _lib
+    from ._lib import check, lib, stream_ptr
     ctx = self.refiner.ctx
-    key = (n_hyp, sigmas, int(iteration), tuple(rgb.shape), rgb.dtype, np.asarray(K, dtype=np.float64).tobytes(), id(self.mesh_tensors['pos']))
-    entry = self._graphs.get(key)
-    if entry is not None and entry['generation'] != ctx.arena_generation():
-      entry = None                                          # the workspace moved: the captured addresses are stale
-    if entry is None:
+    is_np = isinstance(rgb, np.ndarray)
+    is_u8 = (rgb.dtype == np.uint8) if is_np else (rgb.dtype == torch.uint8)
+    H, W = depth.shape[:2]
+    ws = self._track_workspace(n_hyp, sigmas, iteration, (H, W), is_u8, K)
+    # the frame: host arrays go through one pinned staging buffer and ONE host-to-device copy; device tensors that already lie behind
+    # one another as [depth | rgb] (bench.py packs its resident frames that way) are one device copy, others two
+    if is_np or not torch.is_tensor(depth) or not depth.is_cuda:
+      hb = ws['host'].numpy()
+      hb[:H * W * 4].view(np.float32)[:] = np.asarray(depth.cpu() if torch.is_tensor(depth) else depth, dtype=np.float32).reshape(-1)
+      r = np.asarray(rgb.cpu() if torch.is_tensor(rgb) else rgb)
+      if is_u8:
+        hb[H * W * 4:] = r.reshape(-1)
+      else:
+        hb[H * W * 4:].view(np.float32)[:] = r.astype(np.float32, copy=False).reshape(-1)
+      ws['frame'].copy_(ws['host'], non_blocking=True)
+    else:
+      d = depth.to(torch.float)
+      r = rgb if is_u8 else rgb.to(torch.float)
+      packed = (d.is_contiguous() and r.is_contiguous() and d.untyped_storage().data_ptr() == r.untyped_storage().data_ptr() and
+                r.data_ptr() == d.data_ptr() + H * W * 4)
+      if packed:
+        ws['frame'].copy_(torch.as_strided(d.view(torch.uint8).reshape(-1), (ws['frame'].numel(),), (1,)))
+      else:
+        ws['depth'].copy_(d)
+        ws['rgb'].copy_(r)
+    # the pose lives in the workspace and is refined in place; it is (re)loaded only when pose_last was set by someone else (register)
+    if ws['holds_pose'] is not self.pose_last:
+      ws['pose'].copy_(torch.as_tensor(self.pose_last, device=ws['pose'].device, dtype=torch.float).reshape(4, 4))
+    st = torch.cuda.current_stream(ws['pose'].device)
+    if getattr(self, '_graph_on', False):
+      g = ws['graph']
+      if g is not None and g[1] != ctx.arena_generation():
+        g = None                                            # the library's arena moved: the captured addresses are stale
+      if g is None:
+        ctx.reserve(max(64, n_hyp))
+        keep = ws['pose'].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(st)
+        with torch.cuda.stream(side):                        # eager passes first: lazy initialisation, allocator warm-up
+          for _ in range(2):
+            check(lib().fp_track_frame(ctx.handle, ctypes.byref(ws['args']), stream_ptr(ws['pose'].device)))
+            ws['pose'].copy_(keep)
+        st.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+          check(lib().fp_track_frame(ctx.handle, ctypes.byref(ws['args']), stream_ptr(ws['pose'].device)))
+        ws['pose'].copy_(keep)                               # (capturing does not execute)
+        g = ws['graph'] = (graph, ctx.arena_generation())
+      g[0].replay()
+    else:
       ctx.reserve(max(64, n_hyp))
-      st = dict(rgb=rgb.clone(), depth=depth.clone(), pose=pose_in.clone())
-      side = torch.cuda.Stream()
-      side.wait_stream(torch.cuda.current_stream())
-      with torch.cuda.stream(side):                          # eager passes first: lazy initialisation, allocator warm-up
-        for _ in range(2):
-          self._track_frame(st['rgb'], st['depth'], K, st['pose'], iteration, n_hyp, sigmas)
-      torch.cuda.current_stream().wait_stream(side)
-      graph = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(graph):
-        st['out'] = self._track_frame(st['rgb'], st['depth'], K, st['pose'], iteration, n_hyp, sigmas)
-      entry = self._graphs[key] = dict(graph=graph, st=st, generation=ctx.arena_generation())
-    st = entry['st']
-    st['rgb'].copy_(rgb)
-    st['depth'].copy_(depth)
-    st['pose'].copy_(pose_in)
-    entry['graph'].replay()
-    out = st['out']      # the static outputs are overwritten by the next replay: cloned, except the last (the caller copies it to the host at once)
-    return tuple(None if t is None else t.clone() for t in out[:-1]) + (out[-1],)
+      check(lib().fp_track_frame(ctx.handle, ctypes.byref(ws['args']), stream_ptr(ws['pose'].device)))
+    out = ws['pose_of_mesh'].cpu().numpy().reshape(4, 4)      # the frame's one device-to-host copy (synchronises)
+    return out, ws
 
   def track_one(self, rgb, depth, K, iteration, extra={}):
     """src/estimater.py:250-268: refine the previous pose against a new frame (no scoring)."""
     if self.pose_last is None:
       logging.info("Please init pose by register first")
       raise RuntimeError
-    pose_in = self.pose_last
-    pose, _, _, _, pose_of_mesh = self._run_frame(rgb, depth, K, iteration, 1, None)
+    pose_in = torch.as_tensor(self.pose_last).clone() if self.debug >= 2 else None      # (the debug canvas re-refines the frame from it)
+    pose_of_mesh, ws = self._run_frame(rgb, depth, K, iteration, 1, None)
     if self.debug >= 2:            # src/estimater.py:263-266: the refiner's canvas for this frame (debug only: the frame is refined a second time for it)
       d = U.bilateral_filter_depth(U.erode_depth(torch.as_tensor(depth, device='cuda', dtype=torch.float), radius=2, device='cuda'), radius=2, device='cuda')
       xyz_map = U.depth2xyzmap_batch(d[None], np.asarray(K, dtype=np.float32)[None], zfar=np.inf)[0]
       _, extra['vis'] = self.refiner.predict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=d, K=K, glctx=self.glctx,
                                              mesh_diameter=self.diameter, ob_in_cams=pose_in.reshape(-1, 4, 4), normal_map=None, xyz_map=xyz_map,
                                              iteration=iteration, get_vis=True)
-    self.pose_last = pose
-    return pose_of_mesh.data.cpu().numpy().reshape(4, 4)      # src/estimater.py:268: pose @ get_tf_to_centered_mesh() (inside the frame's graph)
+    self.pose_last = ws['pose'].reshape(1, 4, 4)          # src/estimater.py:267: the refiner's (1,4,4) output (a view of the tracking workspace)
+    ws['holds_pose'] = self.pose_last
+    return pose_of_mesh                                   # src/estimater.py:268: pose @ get_tf_to_centered_mesh() (written by the frame's last launch)
 
   def track_multi(self, rgb, depth, K, iteration, n_hypotheses=64, trans_sigma=0.01, rot_sigma_deg=5.0, extra={}):
     """Multi-hypothesis tracking (BASELINE.json configs[4]; a build extension, the reference's track_one refines one pose
-    and never scores): the previous pose and n-1 fixed seeded perturbations of it (tracking.tracking_hypotheses) are refined
+    and never scores): the previous pose and n-1 fixed seeded perturbations of it (tracking.perturbation_set) are refined
     together, scored by ScoreNet, and the best-scoring refined pose becomes `pose_last`.  Same prelude and return value as
-    track_one; `self.poses` / `self.scores` hold all hypotheses of the frame in hypothesis order, `self.best_id` the winner."""
+    track_one; `self.poses` / `self.scores` hold all hypotheses of the frame in hypothesis order, `self.best_id` the winner
+    (views of the tracking workspace: the next frame overwrites them)."""
     if self.pose_last is None:
       logging.info("Please init pose by register first")
       raise RuntimeError
-    pose, self.poses, self.scores, self.best_id, pose_of_mesh = self._run_frame(rgb, depth, K, iteration, int(n_hypotheses),
-                                                                                (float(trans_sigma), float(rot_sigma_deg)))
-    self.pose_last = pose
-    return pose_of_mesh.data.cpu().numpy().reshape(4, 4)
+    pose_of_mesh, ws = self._run_frame(rgb, depth, K, iteration, int(n_hypotheses), (float(trans_sigma), float(rot_sigma_deg)))
+    self.poses, self.scores, self.best_id = ws['poses'], ws['scores'], ws['best'][0]
+    self.pose_last = ws['pose'].reshape(1, 4, 4)
+    ws['holds_pose'] = self.pose_last
+    return pose_of_mesh

@@ -126,17 +126,36 @@ class ScorePredictor:
     return feats
 
   @torch.inference_mode()
-  def score_tail(self, feats, L=None):
-    """att_cross + linear over groups of L hypotheses (score_network.py:82-88): (groups*L,512) -> (groups,L)."""
-    feats = feats.contiguous()
+  def extract_rows_multi(self, objects):
+    """extract_features_multi writing the hypothesis-parallel job's all-gather records: (sum n, 528) rows [feature 512 | pose 16]
+    (dist.py ROW), straight from the library - no concatenation pass.  `score_tail` reads such rows in place."""
+    arr, poses, keep = _lib.object_batches(self.ctx, objects, 'depth')
+    rows = torch.empty((len(poses), 528), dtype=torch.float, device=poses.device)
+    check(lib().fp_score_predict_rows_multi(self.ctx.handle, self.model.handle, arr, len(objects), float(self.cfg['crop_ratio']),
+                                            1 if self.cfg['normalize_xyz'] else 0, ptr(poses), ptr(rows), stream_ptr(poses.device)))
+    return rows
+
+  @torch.inference_mode()
+  def score_tail(self, feats, L=None, score_offset=None):
+    """att_cross + linear over groups of L hypotheses (score_network.py:82-88): (groups*L,512) features - or (groups*L,528) [feature |
+    pose] rows, read in place - -> (groups,L) logits, (groups,) argmax; with `score_offset` also scores = logits + score_offset from
+    the same launch (predict_score.py:209: + 100)."""
+    feats = feats if feats.is_contiguous() else feats.contiguous()
+    assert feats.shape[1] in (512, 528)
+    ld = int(feats.shape[1])
     M = feats.shape[0]
     L = M if L is None else int(L)
     assert M % L == 0
     groups = M // L
     logits = torch.empty((groups, L), dtype=torch.float, device=feats.device)
     argmax = torch.empty((groups,), dtype=torch.int32, device=feats.device)
-    check(lib().fp_score_tail(self.ctx.handle, self.model.handle, ptr(feats), groups, L, ptr(logits), ptr(argmax), stream_ptr(feats.device)))
-    return logits, argmax
+    if score_offset is None and ld == 512:
+      check(lib().fp_score_tail(self.ctx.handle, self.model.handle, ptr(feats), groups, L, ptr(logits), ptr(argmax), stream_ptr(feats.device)))
+      return logits, argmax
+    scores = None if score_offset is None else torch.empty((groups, L), dtype=torch.float, device=feats.device)
+    check(lib().fp_score_tail_scores(self.ctx.handle, self.model.handle, ptr(feats), ld, groups, L, float(score_offset or 0.0), ptr(logits),
+                                     ptr(scores), ptr(argmax), stream_ptr(feats.device)))
+    return (logits, argmax) if score_offset is None else (logits, argmax, scores)
 
   @torch.inference_mode()
   def predict(self, rgb, depth, K, ob_in_cams, normal_map=None, get_vis=False, mesh=None, mesh_tensors=None, glctx=None,
@@ -149,8 +168,8 @@ class ScorePredictor:
     feats = self.extract_features(rgb, depth, K, ob_in_cams, mesh=mesh, mesh_tensors=mesh_tensors, glctx=glctx, mesh_diameter=mesh_diameter)
     # find_best_among_pairs runs ONE forward over all hypotheses (bs == N), so the tournament loop of
     # predict_score.py:206-212 exits in its first round: scores_global = logits + 100
-    logits, _ = self.score_tail(feats, L=len(feats))
-    scores = logits.reshape(-1) + 100
+    _, _, scores = self.score_tail(feats, L=len(feats), score_offset=100.0)          # scores = logits + 100, from the tail's own launch
+    scores = scores.reshape(-1)
     logging.info('forward done')
     if get_vis:
       # predict_score.py:219-224: one row per hypothesis, best first (vis.py: no cv2 here, the labels come in a bitmap font)

@@ -209,6 +209,44 @@ int fp_score_predict_features(fp_ctx *ctx, const fp_net *net, const fp_mesh *mes
                               int H, int W, const double *K, double mesh_diameter, double crop_ratio, int normalize_xyz,
                               const float *d_poses, int N, float *d_feats, void *stream);
 
+/* ---- FoundationPose.track_one (src/estimater.py:250-268) as ONE call: depth prelude (erode -> bilateral -> back-projection, :256-260),
+ *      refinement of the previous pose IN PLACE (:263), pose @ get_tf_to_centered_mesh() (:268) - every launch hand-written, hipGraph-
+ *      capturable, no host synchronisation.  n_hyp > 1 (BASELINE configs[4], a build extension): d_perturb[i] applied to the previous pose
+ *      (R_i = dR_i R, t_i = t + dt_i), all refined, scored (logits + 100, predict_score.py:209); the winner becomes d_pose. ------------- */
+typedef struct fp_track_args {
+  size_t struct_size;              /* = sizeof(fp_track_args) */
+  const fp_net *refine_net, *score_net /* NULL when n_hyp == 1 */;
+  const fp_mesh *mesh;
+  const void *d_rgb;               /* H*W*3: uint8 (rgb_is_u8) or float [0,255] */
+  int rgb_is_u8;
+  const float *d_depth;            /* H*W raw depth, metres */
+  int H, W;
+  const double *K;                 /* host, 3x3 row-major */
+  double mesh_diameter;
+  const fp_refine_cfg *refine_cfg;
+  double score_crop_ratio;
+  int score_normalize_xyz;
+  int iteration;
+  int n_hyp;
+  const float *d_perturb;          /* n_hyp*16 rigid perturbations, the first the identity; NULL when n_hyp == 1 */
+  float model_center[3];           /* get_tf_to_centered_mesh() = translation by -model_center (src/estimater.py:82-86) */
+  float *d_pose;                   /* 16: in = the previous frame's pose (centred mesh), out = this frame's */
+  float *d_pose_of_mesh;           /* 16 out: d_pose @ get_tf_to_centered_mesh(), what track_one returns */
+  float *d_poses, *d_scores;       /* n_hyp > 1: the refined hypotheses (n_hyp*16) and their scores (n_hyp) */
+  int32_t *d_best;                 /* n_hyp > 1: index of the winner */
+  float *d_depth_f, *d_xyz, *d_rgb_f; /* workspace: filtered depth H*W, xyz_map H*W*3, float colours H*W*3 (uint8 frames only) */
+} fp_track_args;
+int fp_track_frame(fp_ctx *ctx, const fp_track_args *args, void *stream);
+
+/* fp_score_tail with a feature row stride (feat_ld >= 512 floats: 528 reads the [feature | pose] rows below in place) and, optionally
+ * (d_scores != NULL), scores = logits + score_offset from the same launch (ScorePredictor.predict: + 100, predict_score.py:209) */
+int fp_score_tail_scores(fp_ctx *ctx, const fp_net *net, const float *d_feats, int feat_ld, int groups, int L, float score_offset, float *d_logits,
+                         float *d_scores, int32_t *d_argmax, void *stream);
+/* fp_score_predict_features_multi writing the hypothesis-parallel job's all-gather records directly: d_rows (sum n) x 528 floats =
+ * [feature 512 | pose 16] per hypothesis (ONE all-gather of these rows precedes the cross-hypothesis tail) */
+int fp_score_predict_rows_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, double crop_ratio,
+                                int normalize_xyz, const float *d_poses, float *d_rows, void *stream);
+
 /* ---- building blocks exported for parity tests and profiling ---------------------------------- */
 /* fp16 NHWC implicit-GEMM convolution on MFMA: out = act(conv(in, w) + bias [+ res]).  w_packed is
  * [Cout][Kpad] fp16 with k = (ky*KW+kx)*Cin + ci, Kpad = roundup(KH*KW*Cin, 32), zero padded. */

@@ -115,9 +115,14 @@ class _FakePredictors:
     w = torch.linspace(-1, 1, 16 * 512).reshape(16, 512)
     return torch.tanh(poses @ w)
 
+  def extract_rows_multi(self, objs):
+    """[feature 512 | pose 16] rows, as ScorePredictor.extract_rows_multi writes them"""
+    poses = torch.cat([torch.as_tensor(o['ob_in_cams']) for o in objs], 0).reshape(-1, 16)
+    return torch.cat((self.extract_features_multi(objs), poses), 1)
+
   def score_tail(self, feats, L=None):
     groups = feats.shape[0] // L
-    f = feats.reshape(groups, L, 512)
+    f = feats[:, :512].reshape(groups, L, 512)         # (rows of 528 are read in place, like the library's tail)
     att = torch.softmax(f @ f.transpose(1, 2) / 512 ** 0.5, -1) @ f
     logits = att.sum(-1)
     return logits, logits.argmax(-1).to(torch.int32)
