@@ -90,12 +90,112 @@ struct HaloCfgD {
   static constexpr int LDS_BYTES = 2 * (LDS_HALFS_MAIN > LDS_HALFS_EPI ? LDS_HALFS_MAIN : LDS_HALFS_EPI);
 };
 
+// Epilogue of a tile (both schedules): residual (staged through LDS) + ReLU (+ positional embedding) in fp32, one rounding to fp16,
+// LDS transpose, 16-byte row-contiguous NHWC stores.
+template <int NT, bool RES, bool POST>
+__device__ __forceinline__ void halo_epilogue(const ConvArgs &p, const int m0, const int c0, f16 *lds, floatx16 (&acc)[2][NT]) {
+  constexpr int NPW = 4, TM = 32 * NT * NPW, NTH = 128 * NPW, PXW = 32 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NPW, wn = wave % NPW;
+  const int lr = lane & 31, lh = lane >> 5;
+  // ---------------- epilogue (as in halo_tile) ----------------
+  f16 *stage = lds;   // [TM px][HL_SLD]
+  constexpr int NRES = TM * 16 / NTH;
+  u32x4 rv[NRES];
+  if constexpr (RES) {
+#pragma unroll
+    for (int u = 0; u < NRES; ++u) {
+      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
+      const int m = min(m0 + px, p.M - 1);
+      rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
+    }
+  }
+  const float lo = p.relu ? 0.f : -__builtin_inff();
+  __syncthreads();          // every wave is done with the band / weight images: the staging tile may overwrite them
+  if constexpr (RES) {
+#pragma unroll
+    for (int u = 0; u < NRES; ++u) {
+      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
+      *reinterpret_cast<u32x4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int pxl = wn * PXW + j * 32 + lr;
+    float4 pvs[2][4];
+    if constexpr (POST) {
+      const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
+    }
+    half4 rq[2][4];
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) rq[i][rg] = *reinterpret_cast<const half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 32 + rg * 8 + lh * 4]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
+        if constexpr (RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][rg][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
+        if constexpr (POST) {
+          const float4 pv = pvs[i][rg];
+          v[0] += pv.x;
+          v[1] += pv.y;
+          v[2] += pv.z;
+          v[3] += pv.w;
+        }
+        half4 hv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
+        *reinterpret_cast<half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 32 + rg * 8 + lh * 4]) = hv;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int NOUT = TM * 16 / NTH, OB = NOUT < 8 ? NOUT : 8;
+#pragma unroll
+  for (int i0 = 0; i0 < NOUT; i0 += OB) {
+    u32x4 ov[OB];
+#pragma unroll
+    for (int u = 0; u < OB; ++u) {
+      if (i0 + u >= NOUT) break;                 // (NOUT = 12 for the 384-pixel tile: the second batch is half full)
+      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
+      ov[u] = *reinterpret_cast<const u32x4 *>(&stage[px * HL_SLD + c16 * 8]);
+    }
+#pragma unroll
+    for (int u = 0; u < OB; ++u) {
+      if (i0 + u >= NOUT) break;
+      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
+      const int m = m0 + px;
+      if (m < p.M) {
+        const bool hi = m >= p.split_m;
+        const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
+        const int coff = hi ? p.coff_hi : 0;
+        *reinterpret_cast<u32x4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
+      }
+    }
+  }
+}
+
 template <int W, int NT, bool RES, bool POST, bool SPLIT = false>
 __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, const int c0, f16 *lds, const int ks = 0) {
   constexpr int NPW = 4, TM = 32 * NT * NPW;
   using C = HaloCfgD<W, TM>;
   constexpr int H = W;
-  constexpr int NTH = 128 * NPW;        // threads
+  // (512 threads)
   constexpr int PXW = 32 * NT;          // pixels per wave
   constexpr int HQ = C::HQ;
   constexpr int WQ = 24 / (2 * NPW);    // weight DMA instructions per wave per group
@@ -300,96 +400,7 @@ __device__ __forceinline__ void halo_tile_dma(const ConvArgs &p, const int m0, c
     }
     return;
   }
-  // ---------------- epilogue (as in halo_tile) ----------------
-  f16 *stage = lds;   // [TM px][HL_SLD]
-  constexpr int NRES = TM * 16 / NTH;
-  u32x4 rv[NRES];
-  if constexpr (RES) {
-#pragma unroll
-    for (int u = 0; u < NRES; ++u) {
-      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
-      const int m = min(m0 + px, p.M - 1);
-      rv[u] = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.Cout + c0 + c16 * 8);
-    }
-  }
-  const float lo = p.relu ? 0.f : -__builtin_inff();
-  __syncthreads();          // every wave is done with the band / weight images: the staging tile may overwrite them
-  if constexpr (RES) {
-#pragma unroll
-    for (int u = 0; u < NRES; ++u) {
-      const int idx = tid + NTH * u, px = idx >> 4, c16 = idx & 15;
-      *reinterpret_cast<u32x4 *>(&stage[px * HL_SLD + c16 * 8]) = rv[u];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int pxl = wn * PXW + j * 32 + lr;
-    float4 pvs[2][4];
-    if constexpr (POST) {
-      const int prow = min(m0 + pxl, p.M - 1) % p.post_period;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-          pvs[i][rg] = *reinterpret_cast<const float4 *>(p.post_add + (size_t)prow * p.Cout + c0 + wm * 64 + i * 32 + rg * 8 + lh * 4);
-    }
-    half4 rq[2][4];
-    if constexpr (RES) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) rq[i][rg] = *reinterpret_cast<const half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 32 + rg * 8 + lh * 4]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        float v[4] = {acc[i][j][rg * 4 + 0], acc[i][j][rg * 4 + 1], acc[i][j][rg * 4 + 2], acc[i][j][rg * 4 + 3]};
-        if constexpr (RES) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rq[i][rg][e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], lo);
-        if constexpr (POST) {
-          const float4 pv = pvs[i][rg];
-          v[0] += pv.x;
-          v[1] += pv.y;
-          v[2] += pv.z;
-          v[3] += pv.w;
-        }
-        half4 hv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[e] = (f16)v[e];
-        *reinterpret_cast<half4 *>(&stage[pxl * HL_SLD + wm * 64 + i * 32 + rg * 8 + lh * 4]) = hv;
-      }
-    }
-  }
-  __syncthreads();
-  constexpr int NOUT = TM * 16 / NTH, OB = NOUT < 8 ? NOUT : 8;
-#pragma unroll
-  for (int i0 = 0; i0 < NOUT; i0 += OB) {
-    u32x4 ov[OB];
-#pragma unroll
-    for (int u = 0; u < OB; ++u) {
-      if (i0 + u >= NOUT) break;                 // (NOUT = 12 for the 384-pixel tile: the second batch is half full)
-      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
-      ov[u] = *reinterpret_cast<const u32x4 *>(&stage[px * HL_SLD + c16 * 8]);
-    }
-#pragma unroll
-    for (int u = 0; u < OB; ++u) {
-      if (i0 + u >= NOUT) break;
-      const int idx = tid + NTH * (i0 + u), px = idx >> 4, c16 = idx & 15;
-      const int m = m0 + px;
-      if (m < p.M) {
-        const bool hi = m >= p.split_m;
-        const long long orow = hi ? (long long)(m - p.split_m) : (long long)m;
-        const int coff = hi ? p.coff_hi : 0;
-        *reinterpret_cast<u32x4 *>((f16 *)p.out + orow * p.out_ld + coff + c0 + c16 * 8) = ov[u];
-      }
-    }
-  }
+  halo_epilogue<NT, RES, POST>(p, m0, c0, lds, acc);
   STAMP(if (lane == 0 && blockIdx.x < 4096) {
     unsigned long long *o = g_halo_stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
     o[0] = t_wait; o[1] = t_body; o[2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32; o[3] = t_loop_end - t_prev; o[4] = t_prev - t_entry;
