@@ -270,7 +270,7 @@ bool conv_wino_supported(const ConvArgs &a);
 size_t wino_packed_halfs(int Cout, int Cin);
 void wino_pack_weights(const float *w_oihw, const float *scale_per_cout, int Cout, int Cin, f16 *out_host);
 int launch_conv_wino(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
-int fp_wino_mode();            // conv.hip: FP_WINO (0: off - the default until measured; 1: every supported 3x3 stride-1 launch)
+int fp_wino_mode();            // conv.hip: FP_WINO (0: off, the default - measured slower or equal, profiles/r05_experiments.md; 1: every supported 3x3 stride-1 launch; 2: the 512-channel layers)
 
 // Column of token t inside the transposed V image [b][4][128][416].  Within each group of 16 tokens the order is
 // {0-3, 8-11, 4-7, 12-15}: the 8 keys that one lane half of the attention kernel's P^T operand carries (the S^T
