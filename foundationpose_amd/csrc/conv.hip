@@ -529,7 +529,8 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const bool halo = conv_halo_supported(a);
   const char *cls = halo ? "conv3x3_halo" : (a.KW == 3) ? "conv3x3_s2" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
-  if (halo && fp_wino_mode() != 0 && (fp_wino_mode() != 2 || a.Cin == 512) && conv_wino_supported(a)) return launch_conv_wino(ctx, a, s);      // (2: the 512-channel layers only)
+  if (halo && fp_wino_mode() != 0 && (fp_wino_mode() != 2 || a.Cin == 512) && (fp_wino_mode() != 3 || a.Cin >= 256) && conv_wino_supported(a))
+    return launch_conv_wino(ctx, a, s);      // (2: the 512-channel layers only; 3: from 256 channels on)
   {
     static const int band = getenv("FP_C128_BAND") ? atoi(getenv("FP_C128_BAND")) : 1;   // conv_s1b.hip (bit-identical to the halo kernel); 0: off, 2: also the 256 -> 256 layers
     // ... from the batch size on at which the general kernel needs more than one round of its 512-pixel tiles (82 images on 256 CUs): below,

@@ -90,9 +90,9 @@ int launch_score_feat(const f16 *att, int Bn, int T, const float *wt, const floa
 __global__ __launch_bounds__(256) void cross_qk_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ wt, const float *__restrict__ bias,
                                                        const double *__restrict__ u, const double *__restrict__ c, int M, float *__restrict__ qk,
                                                        double *__restrict__ sv) {
-  __shared__ float xs[CQ_ROWS][512];
+  __shared__ double xs[CQ_ROWS][512];               // the rows as float64 once: the inner loop converts only the weight
   const int m0 = blockIdx.y * CQ_ROWS, tid = threadIdx.x;
-  for (int i = tid; i < CQ_ROWS * 512; i += 256) xs[i >> 9][i & 511] = x[(size_t)min(m0 + (i >> 9), M - 1) * ldx + (i & 511)];
+  for (int i = tid; i < CQ_ROWS * 512; i += 256) xs[i >> 9][i & 511] = (double)x[(size_t)min(m0 + (i >> 9), M - 1) * ldx + (i & 511)];
   __syncthreads();
   if (blockIdx.x == 4) {
     const int r = tid >> 6, lane = tid & 63;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void cross_qk_kernel(const float *__restrict__
     for (int h = 0; h < 4; ++h) {
       double s = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) s += u[h * 512 + k * 64 + lane] * (double)xs[r][k * 64 + lane];
+      for (int k = 0; k < 8; ++k) s += u[h * 512 + k * 64 + lane] * xs[r][k * 64 + lane];
       s = st_wave_sum(s);
       if (lane == 0) sv[(size_t)(m0 + r) * 4 + h] = s + c[h];
     }
@@ -118,9 +118,11 @@ __global__ __launch_bounds__(256) void cross_qk_kernel(const float *__restrict__
 #pragma unroll
     for (int q = 0; q < 16; ++q) nx[q] = wt[(size_t)(k1 + q) * 1024 + n];
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int q = 0; q < 16; ++q) {
+      const double w = (double)wv[q];
 #pragma unroll
-      for (int r = 0; r < CQ_ROWS; ++r) acc[r] += (double)xs[r][k0 + q] * (double)wv[q];
+      for (int r = 0; r < CQ_ROWS; ++r) acc[r] += xs[r][k0 + q] * w;
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) wv[q] = nx[q];
   }
