@@ -65,6 +65,7 @@ _PROTOS = {
   'fp_render_ex': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(FpRenderOpts), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
   'fp_render_net': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_float, c_void_p, c_void_p]),
   'fp_crop_observed': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p, c_void_p]),
+  'fp_warp_nearest': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
   'fp_erode_depth': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
   'fp_bilateral_filter_depth': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
   'fp_depth2xyzmap': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),

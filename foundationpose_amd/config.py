@@ -53,18 +53,15 @@ def load_run_dir(run_name, weights_root=None):
 def check_network_cfg(cfg, state_dict, stem_key, ref_file):
   """The configurations the HIP networks are built for, checked BEFORE anything touches the device, each refusal naming the
   reference lines whose behaviour would be needed (learning/training/<ref_file>).  Everything else the reference's config
-  offers (use_BN, normalize_xyz, crop_ratio, trans_rep, rot_rep, zfar) is implemented."""
+  offers (use_BN, normalize_xyz, use_normal, crop_ratio, trans_rep, rot_rep, zfar) is implemented."""
   size = tuple(int(x) for x in cfg['input_resize'])
   if size != (160, 160):
     raise NotImplementedError(
       f"input_resize={list(size)}: the HIP trunk is laid out for 160x160 crops (80/40/20-pixel feature maps, 400 tokens = "
       f"pos_embed max_len, network_modules.py:115-137).  The reference renders at input_resize ({ref_file}:38-49, output_size=cfg['input_resize']) "
       f"and only warps side A again when the sizes differ ({ref_file}:64-71); no released model uses another size")
-  if cfg.get('use_normal', False):
-    raise NotImplementedError(
-      f"use_normal=True (9-channel inputs: {ref_file} normalAs/normalBs, src/Utils.py:191-199) is not implemented: no released model has the "
-      f"9-channel stem, and the reference's own estimator cannot reach the branch (src/estimater.py:215,263 call predict() without normal_map, "
-      f"which {ref_file} would hand to torch.as_tensor(None))")
+  # use_normal=True is accepted: the refiner then carries normalAs / normalBs in its BatchPoseData (predict_pose_refine.crop_normals), the
+  # scorer ignores the flag as the reference's does; the networks read 6 channels either way (the c_in check below)
   stem = state_dict.get(stem_key) if hasattr(state_dict, 'get') else None
   if stem is not None:
     c_sd = int(stem.shape[1])

@@ -432,6 +432,12 @@ extern "C" int fp_crop_observed(fp_ctx *ctx, const float *d_rgb, const float *d_
   return launch_crop_observed(a, (hipStream_t)stream);
 }
 
+extern "C" int fp_warp_nearest(fp_ctx *ctx, const float *d_src, int src_batch, int src_h, int src_w, int channels, const float *d_tf, int N,
+                               int out_h, int out_w, float *d_out, void *stream) {
+  FP_REQUIRE(ctx && d_src && d_tf && d_out, "fp_warp_nearest: null argument");
+  return launch_warp_nearest(d_src, src_batch, src_h, src_w, channels, d_tf, N, out_h, out_w, d_out, (hipStream_t)stream);
+}
+
 extern "C" int fp_erode_depth(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
                               float zfar, float *d_out, void *stream) {
   FP_REQUIRE(ctx && d_depth && d_out && H > 0 && W > 0 && radius >= 0, "fp_erode_depth: bad argument");

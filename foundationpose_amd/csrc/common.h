@@ -403,6 +403,8 @@ struct CropArgs {
   void *out;
 };
 int launch_crop_observed(const CropArgs &a, hipStream_t s);
+int launch_warp_nearest(const float *src, int src_batch, int Hs, int Ws, int C, const float *tf, int N, int Ho, int Wo, float *out,
+                        hipStream_t s);
 
 int launch_erode(const float *d, int H, int W, int radius, float diff_thres, float ratio_thres, float zfar, float *out, hipStream_t s);
 int launch_bilateral(const float *d, int H, int W, int radius, float zfar, float sigmaD, float sigmaR, float *out, hipStream_t s);

@@ -139,6 +139,42 @@ int launch_crop_observed(const CropArgs &a, hipStream_t s) {
 }
 
 // ----------------------------------------------------------------------------------------------
+// kornia.warp_perspective(mode='nearest', align_corners=False, zeros padding) of a channel-last image
+// batch with the axis-aligned crop transforms: the warps of the use_normal branch
+// (predict_pose_refine.py:74-76: normalAs = warp(rendered normals (B,h,w,3), tf_to_crops) and
+// normalBs = warp(the frame's normal map, broadcast over B, tf_to_crops)).  Same source coordinate
+// and tie rule as crop_observed_kernel's nearest lookups; output planar (B,C,Ho,Wo) float32.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_nearest_kernel(const float *__restrict__ src, size_t src_batch_stride, int Hs, int Ws, int C,
+                                                           const float *__restrict__ tf, int Ho, int Wo, float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= Ho * Wo) return;
+  const float *T = tf + (size_t)b * 9;
+  const double sx = T[0], tx = T[2], sy = T[4], ty = T[5];
+  const double ax = (1.0 / sx) * Ws / (Ws - 1.0), bx = (-tx / sx) * Ws / (Ws - 1.0) - 0.5;
+  const double ay = (1.0 / sy) * Hs / (Hs - 1.0), by = (-ty / sy) * Hs / (Hs - 1.0) - 0.5;
+  const int j = p / Wo, i = p - j * Wo;
+  const int qx = round_snapped(ax * i + bx), qy = round_snapped(ay * j + by);
+  const bool in = qx >= 0 && qx < Ws && qy >= 0 && qy < Hs;
+  const float *s = src + (size_t)b * src_batch_stride + ((size_t)(in ? qy : 0) * Ws + (in ? qx : 0)) * C;
+  float *o = out + (size_t)b * C * Ho * Wo + p;
+  for (int c = 0; c < C; ++c) o[(size_t)c * Ho * Wo] = in ? s[c] : 0.f;
+}
+
+int launch_warp_nearest(const float *src, int src_batch, int Hs, int Ws, int C, const float *tf, int N, int Ho, int Wo, float *out,
+                        hipStream_t s) {
+  FP_REQUIRE(Hs > 1 && Ws > 1 && Ho > 0 && Wo > 0 && C > 0, "warp_nearest: degenerate image size");
+  FP_REQUIRE(src_batch == 1 || src_batch == N, "warp_nearest: the source batch is 1 (broadcast) or N");
+  if (N == 0) return FP_OK;
+  dim3 grid((Ho * Wo + 255) / 256, N);
+  hipLaunchKernelGGL(warp_nearest_kernel, grid, dim3(256), 0, s, src, src_batch == 1 ? (size_t)0 : (size_t)Hs * Ws * C, Hs, Ws, C, tf, Ho,
+                     Wo, out);
+  FP_CHECK_HIP(hipGetLastError());
+  return FP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // depth pre-processing: the reference's NVIDIA Warp kernels (src/Utils.py:304-395), one thread/pixel
 // ----------------------------------------------------------------------------------------------
 __global__ void erode_depth_kernel(const float *__restrict__ depth, int H, int W, int radius, float diff_thres, float ratio_thres,

@@ -47,8 +47,6 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
   xyz_mapBs are its float32 planar views (fp16 precision).  `dataset` is accepted and ignored: its transform is fused
   into the kernels."""
   cfg = cfg if cfg is not None else {}
-  if cfg.get('use_normal', False) or normal_map is not None:
-    raise NotImplementedError('use_normal=True is not implemented (no released model uses it)')
   ctx = _ctx_of(glctx)
   dev = torch.device('cuda', ctx.device_index)
   if mesh_tensors is None:
@@ -58,12 +56,40 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
   rgb_t = torch.as_tensor(rgb, device=dev, dtype=torch.float).contiguous()
   xyz_t = torch.as_tensor(xyz_map, device=dev, dtype=torch.float).contiguous()
   assert xyz_t.shape[:2] == rgb_t.shape[:2] == tuple(depth.shape[:2])
-  net, tf, _ = crop_net_input(ctx, dm, poses, rgb_t, xyz_t, K, crop_ratio, mesh_diameter, cfg.get('normalize_xyz', False), 0, render_size)
+  net, tf, bbox = crop_net_input(ctx, dm, poses, rgb_t, xyz_t, K, crop_ratio, mesh_diameter, cfg.get('normalize_xyz', False), 0, render_size)
   rgbAs, xyz_mapAs, rgbBs, xyz_mapBs = planar_views(net)
   N = len(poses)
+  normalAs = normalBs = None
+  if cfg.get('use_normal', False):
+    normalAs, normalBs = crop_normals(ctx, dm, poses, tf, bbox, K, rgb_t.shape[:2], render_size, normal_map)
   Ks = torch.as_tensor(np.asarray(K), dtype=torch.float, device=dev).reshape(1, 3, 3).expand(N, 3, 3)
-  return BatchPoseData(rgbAs=rgbAs, rgbBs=rgbBs, xyz_mapAs=xyz_mapAs, xyz_mapBs=xyz_mapBs, poseA=poses, tf_to_crops=tf, Ks=Ks,
-                       mesh_diameters=torch.full((N,), float(mesh_diameter), device=dev), net_input=net)
+  return BatchPoseData(rgbAs=rgbAs, rgbBs=rgbBs, normalAs=normalAs, normalBs=normalBs, xyz_mapAs=xyz_mapAs, xyz_mapBs=xyz_mapBs, poseA=poses,
+                       tf_to_crops=tf, Ks=Ks, mesh_diameters=torch.full((N,), float(mesh_diameter), device=dev), net_input=net)
+
+
+def crop_normals(ctx, dm, poses, tf, bbox, K, frame_hw, render_size, normal_map):
+  """The use_normal branch of predict_pose_refine.py:49,58,74-76.  normalAs: the camera-frame normals rendered INTO the
+  crop (nvdiffrast_render(get_normal=True, output_size=input_resize, bbox2d=...), src/Utils.py:193-197) and then warped
+  by tf_to_crops once more, nearest - the reference does that unconditionally for the normals (its rgb / xyz of side A
+  are only re-warped when the sizes differ), so normalAs is the crop of a crop; kept as it is.  normalBs: the frame's
+  normal map cropped by tf_to_crops, nearest.  Neither is touched by transform_batch (h5_dataset.py:79-127) and neither
+  is fed to RefineNet (predict_pose_refine.py:186-187 builds A and B from rgb and xyz_map only): they ride in
+  BatchPoseData.  A missing normal_map fails where the reference's torch.as_tensor(None) does."""
+  dev = poses.device
+  N = len(poses)
+  H, W = int(frame_hw[0]), int(frame_hw[1])
+  h, w = int(render_size[0]), int(render_size[1])
+  Kd, Kp = k_ptr(K)
+  s = stream_ptr(dev)
+  normal_t = torch.as_tensor(normal_map, dtype=torch.float, device=dev).contiguous()     # (H,W,3); None raises here as in the reference
+  assert normal_t.shape == (H, W, 3), f'normal_map is {tuple(normal_t.shape)}, the frame is {(H, W)}'
+  rendered = torch.empty((N, h, w, 3), device=dev, dtype=torch.float)
+  check(lib().fp_render(ctx.handle, dm.handle, ptr(poses), N, Kp, H, W, ptr(bbox), h, w, 1, 0.8, 0.5, None, None, ptr(rendered), None, s))
+  normalAs = torch.empty((N, 3, h, w), device=dev, dtype=torch.float)
+  normalBs = torch.empty((N, 3, h, w), device=dev, dtype=torch.float)
+  check(lib().fp_warp_nearest(ctx.handle, ptr(rendered), N, h, w, 3, ptr(tf), N, h, w, ptr(normalAs), s))
+  check(lib().fp_warp_nearest(ctx.handle, ptr(normal_t), 1, H, W, 3, ptr(tf), N, h, w, ptr(normalBs), s))
+  return normalAs, normalBs
 
 
 class PoseRefinePredictor:
@@ -186,6 +212,15 @@ class PoseRefinePredictor:
     logging.info(f'ob_in_cams:{np.shape(ob_in_cams)}')
     if self.cfg['rot_rep'] not in ('axis_angle', '6d'):
       raise RuntimeError
+    # predict_pose_refine.py:161-163: the normal map only exists under use_normal.  There the reference warps it in every iteration
+    # into pose_data.normalAs / normalBs, which predict() itself never reads (A and B are rgb + xyz_map, :186-187): the refined poses do
+    # not depend on it, so the fused passes leave those warps out; make_crop_data_batch (the stepping API, get_vis) makes them.
+    if not self.cfg['use_normal']:
+      normal_map = None
+    elif normal_map is None:
+      raise RuntimeError('Could not infer dtype of NoneType (use_normal=True needs normal_map: predict_pose_refine.py:75 hands it to torch.as_tensor)')
+    elif tuple(np.shape(normal_map)) != tuple(np.shape(rgb)):
+      raise RuntimeError(f'normal_map {np.shape(normal_map)} does not match the frame {np.shape(rgb)}')
     ctx = _ctx_of(glctx, self.device) if glctx is not None else self.ctx
     dev = torch.device('cuda', ctx.device_index)
     if mesh_tensors is None:
@@ -209,7 +244,7 @@ class PoseRefinePredictor:
       # predict_pose_refine.py:241-293: crops at the start poses and at the refined ones, side by side (vis.py: no cv2 here, the labels come in a bitmap font)
       from .vis import refine_canvas
       logging.info("get_vis...")
-      kw = dict(mesh_diameter=mesh_diameter, cfg=self.cfg, glctx=glctx, mesh_tensors=mesh_tensors)
+      kw = dict(mesh_diameter=mesh_diameter, cfg=self.cfg, glctx=glctx, mesh_tensors=mesh_tensors, normal_map=normal_map)
       before = make_crop_data_batch(self.cfg['input_resize'], ob_in_cams, mesh, rgb, depth, K, self.cfg['crop_ratio'], xyz_map, **kw)
       after = make_crop_data_batch(self.cfg['input_resize'], poses, mesh, rgb, depth, K, self.cfg['crop_ratio'], xyz_map, **kw)
       return poses, refine_canvas(before, after)

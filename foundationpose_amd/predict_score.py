@@ -19,8 +19,8 @@ def make_crop_data_batch(render_size, ob_in_cams, mesh, rgb, depth, K, crop_rati
   Side B's xyz comes from the cropped depth through the full-resolution round trip of h5_dataset.py:158-161, composed
   per pixel inside fp_crop_observed.  depthAs / depthBs are float32 (render depth; nearest crop of `depth`)."""
   cfg = cfg if cfg is not None else {}
-  if cfg.get('use_normal', False) or normal_map is not None:
-    raise NotImplementedError('use_normal=True is not implemented (no released model uses it)')
+  # cfg['use_normal'] only makes the reference's render compute normals it then drops (predict_score.py:79 get_normal=..., normal_r
+  # unused; :103-104 normalAs = normalBs = None whatever the flag), and `normal_map` is never read: both change nothing here
   ctx = _ctx_of(glctx)
   dev = torch.device('cuda', ctx.device_index)
   if mesh_tensors is None:

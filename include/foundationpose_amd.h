@@ -107,6 +107,14 @@ int fp_crop_observed(fp_ctx *ctx, const float *d_rgb, const float *d_geom, int H
                      const float *d_tf, const float *d_poses, int N, int out_h, int out_w, int mode,
                      double mesh_diameter, int normalize_xyz, int out_fmt, void *d_out, void *stream);
 
+/* ---- a12, the use_normal branch: kornia.warp_perspective(mode='nearest', align_corners=False, zeros padding) of a
+ *      channel-last float image batch by the axis-aligned crop transforms (predict_pose_refine.py:74-76: normalAs from
+ *      the rendered normals, normalBs from the frame's normal map).  d_src: src_batch x src_h x src_w x channels with
+ *      src_batch == N, or 1 = one image for every transform (the reference's .expand(B,-1,-1,-1)); d_tf: N x 3x3;
+ *      d_out: N x channels x out_h x out_w (planar, as the reference's BatchPoseData holds it). */
+int fp_warp_nearest(fp_ctx *ctx, const float *d_src, int src_batch, int src_h, int src_w, int channels, const float *d_tf, int N,
+                    int out_h, int out_w, float *d_out, void *stream);
+
 /* ---- a6/a7/a8: depth pre-processing (src/Utils.py:304-438) ----------------------------------- */
 int fp_erode_depth(fp_ctx *ctx, const float *d_depth, int H, int W, int radius, float depth_diff_thres, float ratio_thres,
                    float zfar, float *d_out, void *stream);

@@ -17,16 +17,18 @@ DEFAULT_SCORE_CFG = dict(input_resize=(160, 160), c_in=6, use_BN=True, normalize
                          crop_ratio=1.1)
 
 
-def _render_batch(cfg, K, H, W, poseA, mesh_tensors, tf_to_crops):
+def _render_batch(cfg, K, H, W, poseA, mesh_tensors, tf_to_crops, want_normal=False):
   """predict_pose_refine.py:44-56 / predict_score.py:71-86: render at input_resize inside bbox2d_ori."""
   bbox2d_ori = G.crop_bbox2d_ori(tf_to_crops, cfg['input_resize'])
   extra = {}
-  rgb_r, depth_r, _ = nvdiffrast_render(K=K, H=H, W=W, ob_in_cams=poseA, get_normal=cfg['use_normal'],
-                                        mesh_tensors=mesh_tensors, output_size=cfg['input_resize'],
-                                        bbox2d=bbox2d_ori, use_light=True, extra=extra)
+  rgb_r, depth_r, normal_r = nvdiffrast_render(K=K, H=H, W=W, ob_in_cams=poseA, get_normal=cfg['use_normal'],
+                                               mesh_tensors=mesh_tensors, output_size=cfg['input_resize'],
+                                               bbox2d=bbox2d_ori, use_light=True, extra=extra)
   rgb_rs = rgb_r.permute(0, 3, 1, 2) * 255
   depth_rs = depth_r[..., None].permute(0, 3, 1, 2)
   xyz_map_rs = extra['xyz_map'].permute(0, 3, 1, 2)
+  if want_normal:
+    return rgb_rs, depth_rs, xyz_map_rs, normal_r.permute(0, 3, 1, 2)
   return rgb_rs, depth_rs, xyz_map_rs
 
 
@@ -46,15 +48,24 @@ def _xyz_transform(xyz, poseA, mesh_diameters, normalize_xyz, invalid_thres, inv
   return xyz
 
 
-def make_crop_data_batch_refine(cfg, ob_in_cams, mesh_tensors, rgb, depth, K, xyz_map, mesh_diameter):
+def make_crop_data_batch_refine(cfg, ob_in_cams, mesh_tensors, rgb, depth, K, xyz_map, mesh_diameter, normal_map=None):
   """predict_pose_refine.py:26-89 + PairH5Dataset.transform_batch (h5_dataset.py:79-127,210-219).
-  rgb (H,W,3) float tensor [0,255], xyz_map (H,W,3).  Returns dict of network-ready tensors."""
+  rgb (H,W,3) float tensor [0,255], xyz_map (H,W,3).  Returns dict of network-ready tensors.  Under cfg['use_normal']
+  also normalAs / normalBs (:74-76: BOTH warped by tf_to_crops, nearest - the rendered normals are in crop coordinates
+  already, the reference warps them again regardless; transform_batch leaves them alone)."""
   H, W = depth.shape[:2]
   render_size = cfg['input_resize']
   poseA = torch.as_tensor(ob_in_cams, dtype=torch.float32)
   B = len(poseA)
   tf_to_crops = G.compute_crop_window_tf_batch(poseA, K, cfg['crop_ratio'], (render_size[1], render_size[0]), mesh_diameter)
-  rgb_rs, _, xyz_map_rs = _render_batch(cfg, K, H, W, poseA, mesh_tensors, tf_to_crops)
+  normals = {}
+  if cfg.get('use_normal', False):
+    rgb_rs, _, xyz_map_rs, normal_rs = _render_batch(cfg, K, H, W, poseA, mesh_tensors, tf_to_crops, want_normal=True)
+    normals['normalAs'] = warp_perspective_nearest(normal_rs.contiguous(), tf_to_crops, render_size)
+    nm = torch.as_tensor(normal_map, dtype=torch.float32)
+    normals['normalBs'] = warp_perspective_nearest(nm.permute(2, 0, 1)[None].expand(B, -1, -1, -1).contiguous(), tf_to_crops, render_size)
+  else:
+    rgb_rs, _, xyz_map_rs = _render_batch(cfg, K, H, W, poseA, mesh_tensors, tf_to_crops)
   rgbBs = warp_perspective(rgb.permute(2, 0, 1)[None].expand(B, -1, -1, -1), tf_to_crops, dsize=render_size, mode='bilinear', align_corners=False)
   xyz_mapBs = warp_perspective_nearest(xyz_map.permute(2, 0, 1)[None].expand(B, -1, -1, -1).contiguous(), tf_to_crops, render_size)
   mesh_diameters = torch.ones((B,), dtype=torch.float32) * mesh_diameter
@@ -62,7 +73,7 @@ def make_crop_data_batch_refine(cfg, ob_in_cams, mesh_tensors, rgb, depth, K, xy
   rgbBs = rgbBs / 255.0
   xyz_mapAs = _xyz_transform(xyz_map_rs, poseA, mesh_diameters, cfg['normalize_xyz'], 0.001, False)
   xyz_mapBs = _xyz_transform(xyz_mapBs, poseA, mesh_diameters, cfg['normalize_xyz'], 0.001, False)
-  return dict(rgbAs=rgbAs, rgbBs=rgbBs, xyz_mapAs=xyz_mapAs, xyz_mapBs=xyz_mapBs, poseA=poseA, tf_to_crops=tf_to_crops)
+  return dict(rgbAs=rgbAs, rgbBs=rgbBs, xyz_mapAs=xyz_mapAs, xyz_mapBs=xyz_mapBs, poseA=poseA, tf_to_crops=tf_to_crops, **normals)
 
 
 def make_crop_data_batch_score(cfg, ob_in_cams, mesh_tensors, rgb, depth, K, mesh_diameter):

@@ -124,8 +124,7 @@ def test_unsupported_network_configs_are_refused_with_the_reference_line():
   for P, sd, base, ref in ((PoseRefinePredictor, rsd, C.REFINE_DEFAULT, 'predict_pose_refine.py'), (ScorePredictor, ssd, C.SCORE_DEFAULT, 'predict_score.py')):
     with pytest.raises(NotImplementedError, match=ref + ':64-71'):
       P(state_dict=sd, cfg=dict(base, input_resize=[128, 128]))
-    with pytest.raises(NotImplementedError, match='src/Utils.py:191-199'):
-      P(state_dict=sd, cfg=dict(base, use_normal=True))
+    C.check_network_cfg(dict(base, use_normal=True), sd, next(iter(sd)), ref)      # accepted since round 5 (tests/test_gpu_kernels.py: use_normal)
     cfg4 = dict(base)
     cfg4.pop('c_in')                     # the reference's back-compat default c_in=4 meets a 6-channel checkpoint: load_state_dict raises there
     with pytest.raises(ValueError, match='c_in=4'):
