@@ -64,7 +64,7 @@ static int g_one_chain = 0;      // FP_ONE_CHAIN=1: the two sides of encodeA as 
 
 int fp_set_kernel_attributes(fp_ctx *ctx) {
   std::vector<KernelLds> v;
-  conv_kernel_lds(v), conv_halo_kernel_lds(v), conv_s1b_kernel_lds(v), conv_wino_kernel_lds(v), conv_s2_kernel_lds(v), stem_kernel_lds(v);
+  conv_kernel_lds(v), conv_halo_kernel_lds(v), conv_s1b_kernel_lds(v), conv_small_kernel_lds(v), conv_wino_kernel_lds(v), conv_s2_kernel_lds(v), stem_kernel_lds(v);
   tok_gemm_kernel_lds(v), tok_qkv_kernel_lds(v), head_mlp_kernel_lds(v), attn_kernel_lds(v), raster_kernel_lds(v);
   FP_CHECK_HIP(hipSetDevice(ctx->device));
   for (const KernelLds &k : v)
@@ -877,7 +877,19 @@ extern "C" int fp_conv2d_f16(fp_ctx *ctx, const void *d_in, int Nimg, int H, int
   a.split_m = 0x7fffffff;
   a.post_period = 1;
   a.tokens = 400;
-  // launches of a few workgroups take the split-K form of the 3x3 stride-1 kernel, as inside the networks (1 .. 4 hypotheses)
+  // a few images of a 3x3 stride-1 trunk layer: conv_small.hip on weights packed here, as inside the networks (a tracking frame)
+  if (!out_f32 && conv_small_shape(a, ctx->num_cu)) {
+    const size_t bytes = small_packed_halfs(Cout, Cin) * sizeof(f16);
+    FP_TRY(fp_arena_ensure(ctx, bytes + 4096));
+    const size_t mark = ctx->arena.off;
+    f16 *pk = (f16 *)ctx->arena.take(bytes);
+    int rc = pk ? small_pack_weights(a.w, Cout, Cin, a.Kpad, pk, (hipStream_t)stream) : FP_ENOMEM;
+    a.wsm = pk;
+    if (rc == FP_OK) rc = launch_conv(ctx, a, (hipStream_t)stream);
+    ctx->arena.off = mark;
+    return rc;
+  }
+  // launches of a few workgroups take the split-K form of the 3x3 stride-1 kernel, as inside the networks (2 .. 4 hypotheses)
   a.ksplit = out_f32 ? 0 : conv_ksplit(a, ctx->num_cu);
   if (a.ksplit > 1) {
     const size_t bytes = (size_t)a.ksplit * a.M * a.Cout * sizeof(float);

@@ -222,6 +222,7 @@ struct KernelLds {
 void conv_kernel_lds(std::vector<KernelLds> &v);        // conv.hip
 void conv_halo_kernel_lds(std::vector<KernelLds> &v);   // conv_halo.hip
 void conv_s1b_kernel_lds(std::vector<KernelLds> &v);    // conv_s1b.hip
+void conv_small_kernel_lds(std::vector<KernelLds> &v);  // conv_small.hip
 void conv_wino_kernel_lds(std::vector<KernelLds> &v);   // conv_wino.hip
 void conv_s2_kernel_lds(std::vector<KernelLds> &v);     // conv_s2.hip
 void stem_kernel_lds(std::vector<KernelLds> &v);        // stem.hip
@@ -252,6 +253,8 @@ struct ConvArgs {
   const f16 *wpk = nullptr;
   // 3x3 stride-1 layers: the Winograd F(2,3)-along-rows image of the fp32 weights (conv_wino.hip: wino_pack_weights); nullptr: the direct kernels run
   const f16 *wwino = nullptr;
+  // 3x3 stride-1 layers: the weights in the fragment order of conv_small.hip (small_pack_weights); nullptr: that form is not used
+  const f16 *wsm = nullptr;
 };
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 // conv_s2.hip: band-in-LDS form of the 3x3 stride-2 layers
@@ -264,6 +267,13 @@ int launch_conv_s2(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 // conv_s1b.hip: band-in-LDS form of the 128 -> 128 stride-1 layers on 40x40 maps (bit-identical to the halo kernel; FP_C128_BAND=0: off)
 bool s1b_supported(const ConvArgs &a);
 int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
+
+// conv_small.hip: the 3x3 stride-1 layers in launches of a few images (tracking; 1 .. 4 hypotheses): 32 x 32 tiles, K split over the waves of a workgroup
+bool conv_small_shape(const ConvArgs &a, int num_cu);     // the layer shapes and launch sizes it runs
+bool conv_small_use(const ConvArgs &a, int num_cu);       // ... and the caller holds the packed weights (ConvArgs::wsm)
+size_t small_packed_halfs(int Cout, int Cin);
+int small_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s);
+int launch_conv_small(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
 // conv_wino.hip: Winograd F(2,3) along rows for the 3x3 stride-1 layers (its own numerics: transformed weights and inputs in fp16)
 bool conv_wino_supported(const ConvArgs &a);

@@ -462,6 +462,7 @@ int conv_halo_ksplit(const ConvArgs &a, int num_cu);                     // conv
 // Split factor of a launch (0: none): the 3x3 stride-1 layers by conv_halo_ksplit; the 3x3 stride-2 layer from 36 K-steps on when
 // its 64-pixel tiles fill at most a quarter of the workgroup slots (1 .. 4 hypotheses).  Decided by the caller that owns the scratch.
 int conv_ksplit(const ConvArgs &a, int num_cu) {
+  if (conv_small_use(a, num_cu)) return 0;           // conv_small.hip splits K inside its workgroups
   if (const int k = conv_halo_ksplit(a, num_cu)) return k;
   const int nk = a.Kpad / C2_BK;
   if (a.KH == 3 && a.KW == 3 && a.stride == 2 && a.out_mode == 0 && a.Cin % 32 == 0 && a.Cout % 128 == 0 && a.M < S2_MIN_PIXELS && nk >= 36 && nk % 4 == 0 &&
@@ -529,6 +530,7 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const bool halo = conv_halo_supported(a);
   const char *cls = halo ? "conv3x3_halo" : (a.KW == 3) ? "conv3x3_s2" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
+  if (halo && !(a.splitk && a.ksplit > 1) && conv_small_use(a, ctx->num_cu)) return launch_conv_small(ctx, a, s);      // a few images: conv_small.hip
   if (halo && fp_wino_mode() != 0 && (fp_wino_mode() != 2 || a.Cin == 512) && (fp_wino_mode() != 3 || a.Cin >= 256) && conv_wino_supported(a))
     return launch_conv_wino(ctx, a, s);      // (2: the 512-channel layers only; 3: from 256 channels on)
   {

@@ -12,6 +12,7 @@ struct ConvW {
   f16 *w = nullptr;
   f16 *wpk = nullptr;     // 3x3 stride-2 layers: the same weights in the fragment order of conv_s2.hip
   f16 *wwino = nullptr;   // 3x3 stride-1 layers from 128 channels on: the Winograd image of the fp32 weights (conv_wino.hip)
+  f16 *wsm = nullptr;     // 3x3 stride-1 layers with 128 / 256 / 512 input channels: fragment order of conv_small.hip (launches of a few images)
   float *bias = nullptr;
   int Cin = 0, Cout = 0, K = 1, Kpad = 0, stride = 1;
 };
@@ -155,6 +156,14 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
     net->allocs.push_back(pk);
     out->wpk = (f16 *)pk;
     FP_TRY(s2_pack_weights(out->w, Cout, CinP, Kpad, out->wpk, nullptr, stride == 1 ? 2 : 0, stride == 1 ? 1 : 0));      // (conv_s1b.hip: 64 couts per wave group)
+    FP_CHECK_HIP(hipStreamSynchronize(nullptr));
+  }
+  if (K == 3 && stride == 1 && (CinP == 128 || CinP == 256 || CinP == 512) && Cout % 32 == 0 && Kpad == 9 * CinP) {
+    void *pk = nullptr;
+    FP_CHECK_HIP(hipMalloc(&pk, small_packed_halfs(Cout, CinP) * sizeof(f16)));
+    net->allocs.push_back(pk);
+    out->wsm = (f16 *)pk;
+    FP_TRY(small_pack_weights(out->w, Cout, CinP, Kpad, out->wsm, nullptr));
     FP_CHECK_HIP(hipStreamSynchronize(nullptr));
   }
   return FP_OK;
@@ -366,6 +375,7 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
   a.w = w.w;
   a.wpk = w.wpk;
   a.wwino = w.wwino;
+  a.wsm = w.wsm;
   a.bias = w.bias;
   a.res = c.res;
   a.post_add = c.post_add;

@@ -17,6 +17,9 @@ SHAPES = {  # name: (N, H, W, Cin, Cout, k, stride, res)
   'trk_128': (1, 40, 40, 128, 128, 3, 1, True),        # tracking, one hypothesis: a side's encodeA layer (13 tiles of 128 px)
   'trk_256': (1, 40, 40, 256, 256, 3, 1, True),        # ... encodeAB at 40x40 (split-K)
   'trk_512': (1, 20, 20, 512, 512, 3, 1, True),        # ... encodeAB at 20x20 (split-K)
+  'trk2_128': (2, 40, 40, 128, 128, 3, 1, True), 'trk2_256': (2, 40, 40, 256, 256, 3, 1, True), 'trk2_512': (2, 20, 20, 512, 512, 3, 1, True),
+  'trk4_128': (4, 40, 40, 128, 128, 3, 1, True), 'trk4_256': (4, 40, 40, 256, 256, 3, 1, True), 'trk4_512': (4, 20, 20, 512, 512, 3, 1, True),
+  'trk8_128': (8, 40, 40, 128, 128, 3, 1, True), 'trk8_256': (8, 40, 40, 256, 256, 3, 1, True), 'trk8_512': (8, 20, 20, 512, 512, 3, 1, True),
 }
 
 def main():

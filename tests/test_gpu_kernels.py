@@ -245,22 +245,30 @@ def test_use_normal_branch(sc, fp):
   assert float((ref['normalBs'] != 0).float().mean()) > 0.3
   frac, mx, _ = util.mismatch_report(ref['normalAs'].numpy(), pd.normalAs.cpu().numpy(), 2e-5)
   assert frac <= 5e-4, f'normalAs: {frac:.2e} (max {mx:.2e})'
+  # (the reference's second warp samples the 160x160 crop at FRAME coordinates of the window, so most of normalAs is out of bounds = 0:
+  # reproduced, not repaired; the rendered normals themselves are checked below and in the rasteriser tests)
   cov = (ref['normalAs'] != 0).any(1)
-  assert 0.02 < float(cov.float().mean()) < 0.9
-  nrm = torch.linalg.norm(pd.normalAs.cpu(), dim=1)[cov]
-  assert float((nrm - 1).abs().max()) < 1e-5                       # F.normalize'd (src/Utils.py:196)
+  assert float(cov.float().mean()) < 0.9
+  _, _, nr = fp['U'].nvdiffrast_render(K=sc['K'], H=480, W=640, ob_in_cams=torch.from_numpy(poses).cuda(), mesh_tensors=mt, get_normal=True,
+                                       output_size=(160, 160), bbox2d=G.crop_bbox2d_ori(pd.tf_to_crops.cpu(), (160, 160)))
+  hit = (nr != 0).any(-1)
+  assert 0.02 < float(hit.float().mean()) < 0.9 and float((torch.linalg.norm(nr, dim=-1)[hit] - 1).abs().max()) < 1e-5      # F.normalize'd (src/Utils.py:196)
+  want_a = OW.warp_perspective_nearest(nr.cpu().permute(0, 3, 1, 2).contiguous(), pd.tf_to_crops.cpu(), (160, 160))
+  frac, mx, _ = util.mismatch_report(want_a.numpy(), pd.normalAs.cpu().numpy(), 0.0)      # the second warp alone, on the HIP render
+  assert frac <= 5e-4, f'normalAs (second warp): {frac:.2e} (max {mx:.2e})'
   for k in ('rgbAs', 'xyz_mapAs', 'rgbBs', 'xyz_mapBs'):          # the other fields as without the flag
     frac, mx, _ = util.mismatch_report(ref[k].numpy(), getattr(pd, k).cpu().numpy(), 1.5e-3)
     assert frac <= 5e-4, f'{k}: {frac:.2e} (max {mx:.3f})'
   # the generic warp itself, on a source batch (not broadcast) with a non-square source: against the oracle's kornia restatement
   src = torch.from_numpy(rng.standard_normal((n, 37, 53, 2)).astype(np.float32))
-  tf = pd.tf_to_crops.cpu().clone()
-  tf[:, 0, 0] *= 0.11; tf[:, 1, 1] *= 0.09; tf[:, 0, 2] = tf[:, 0, 2] * 0.11 + 3.3; tf[:, 1, 2] = tf[:, 1, 2] * 0.09 - 2.2
+  tf = torch.eye(3).repeat(n, 1, 1)                                # x_dst = sx x_src + tx: part of every output falls outside the source
+  tf[:, 0, 0] = torch.linspace(0.7, 1.3, n); tf[:, 1, 1] = torch.linspace(0.9, 0.6, n)
+  tf[:, 0, 2] = torch.linspace(-6.0, 4.0, n); tf[:, 1, 2] = torch.linspace(3.0, -5.0, n)
   want = OW.warp_perspective_nearest(src.permute(0, 3, 1, 2).contiguous(), tf, (24, 40))
   got = torch.empty((n, 2, 24, 40), device='cuda')
   tfd, srcd = tf.cuda().contiguous(), src.cuda().contiguous()
   check(lib().fp_warp_nearest(fp['ctx'].handle, ptr(srcd), n, 37, 53, 2, ptr(tfd), n, 24, 40, ptr(got), stream_ptr()))
-  assert torch.equal(got.cpu(), want) and float((want != 0).float().mean()) > 0.1
+  assert torch.equal(got.cpu(), want) and 0.3 < float((want != 0).float().mean()) < 0.98
   with pytest.raises(RuntimeError, match='source batch'):
     check(lib().fp_warp_nearest(fp['ctx'].handle, ptr(srcd), 2, 37, 53, 2, ptr(tfd), n, 24, 40, ptr(got), stream_ptr()))
   # predict(): same poses with and without the flag; the reference's failure without a normal map; ignored without the flag
@@ -463,10 +471,13 @@ def _pack_conv_weight(w, cin_pad):
   (9, 40, 40, 256, 512, 3, 2, False, True),         # band-in-LDS stride-2 kernel (conv_s2.hip): 8-row tiles straddle images, last tile partial
   (9, 40, 40, 64, 128, 3, 2, False, False),         # the same with 128-cout blocks, no ReLU
   (2, 160, 160, 6, 64, 7, 2, False, True),
-  (1, 20, 20, 512, 512, 3, 1, True, True),          # one hypothesis: 16 quarter tiles -> split-K, 8 shares of 2 chunks + finishing pass
+  (1, 20, 20, 512, 512, 3, 1, True, True),          # one hypothesis: conv_small.hip (13 x 16 workgroups; FP_SMALL=0: split-K, 8 shares of 2 chunks + finishing pass)
   (1, 40, 40, 256, 256, 3, 1, False, True),         # split-K, 4 shares of 2 chunks
   (2, 40, 40, 128, 128, 3, 1, True, False),         # 26 quarter tiles of a 128-channel layer: too few chunks to split, one launch of 128-pixel tiles, no ReLU
   (2, 40, 40, 256, 256, 3, 1, True, False),         # split-K, 4 shares of 2 chunks, residual, no ReLU
+  (1, 40, 40, 128, 128, 3, 1, True, True),          # conv_small.hip (a few images: 32 x 32 tiles, K split over the waves): 50 x 4 workgroups
+  (3, 20, 20, 512, 512, 3, 1, True, False),         # ... tiles that straddle images, last tile partial (1200 pixels), no ReLU
+  (1, 40, 40, 256, 128, 3, 1, False, True),         # ... Cout != Cin
   (1, 40, 40, 256, 512, 3, 2, False, True),         # stride 2, 72 K-steps at one hypothesis: split-K of the implicit GEMM (4 shares of 18 steps), last 64-pixel tile partial
   (4, 40, 40, 256, 512, 3, 2, False, False),        # the same at the largest batch that takes it (1600 pixels), no ReLU
   (1, 1, 1000, 512, 1024, 1, 1, False, False),     # a Linear layer (1x1, M=1000 tokens: ragged last tile)
