@@ -255,6 +255,9 @@ struct ConvArgs {
   const f16 *wwino = nullptr;
   // 3x3 stride-1 layers: the weights in the fragment order of conv_small.hip (small_pack_weights); nullptr: that form is not used
   const f16 *wsm = nullptr;
+  // hypotheses of the network pass this launch belongs to (0: a stand-alone call): the few-image form is chosen by it, so that the two sides
+  // of encodeA as one chain or two (twice the images per launch) take the same kernel
+  int hyp = 0;
 };
 int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 // conv_s2.hip: band-in-LDS form of the 3x3 stride-2 layers
@@ -394,6 +397,8 @@ struct RenderPlan {
   int S, strip_rows, lds_verts;         // strips per hypothesis, rows per strip, whether the triangle pass keeps the vertex records in LDS
   int G, Fg;                            // face ranges per hypothesis in the classification, faces per range
   size_t lds_bytes, a_lds, c_bytes, b_bytes, a_bytes, count_bytes, list_bytes, total;
+  int solo;                             // one or two hypotheses: the whole render in the strip kernel's launch (raster.hip: render_kernel<.., true>)
+  size_t solo_lds;
 };
 RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu);
 // A render of N hypotheses goes out in sub-batches of render_chunk(...) when the worst-case scratch of all N at once (two face lists of

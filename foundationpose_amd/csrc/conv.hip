@@ -530,7 +530,7 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   const bool halo = conv_halo_supported(a);
   const char *cls = halo ? "conv3x3_halo" : (a.KW == 3) ? "conv3x3_s2" : (a.KW == 7 ? "conv7x7" : "linear");
   ProfScope ps(ctx, s, cls, flops);
-  if (halo && !(a.splitk && a.ksplit > 1) && conv_small_use(a, ctx->num_cu)) return launch_conv_small(ctx, a, s);      // a few images: conv_small.hip
+  if (!(a.splitk && a.ksplit > 1) && conv_small_use(a, ctx->num_cu)) return launch_conv_small(ctx, a, s);      // a few images: conv_small.hip
   if (halo && fp_wino_mode() != 0 && (fp_wino_mode() != 2 || a.Cin == 512) && (fp_wino_mode() != 3 || a.Cin >= 256) && conv_wino_supported(a))
     return launch_conv_wino(ctx, a, s);      // (2: the 512-channel layers only; 3: from 256 channels on)
   {

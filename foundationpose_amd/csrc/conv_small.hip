@@ -28,20 +28,25 @@ namespace {
 constexpr int SM_NW = 8;       // waves per workgroup = shares of the input channels
 constexpr int SM_LD = 36;      // floats per pixel row of a partial tile in LDS (32 couts + 4: 16-byte rows, spread over the banks)
 
-template <int KS, int HW>
+template <int KS, int HW, int ST>
 struct SmallCfg {
   static constexpr int CIN = 128 * KS;
   static constexpr int PITCH = CIN + 8;                 // halfs per staged pixel
-  static constexpr int SPAN = 32 + 2 * HW + 2;          // pixels m0 - HW - 1 .. m0 + 31 + HW + 1
+  // input pixels (flat NHWC index) from the first tap of output pixel m0 to the last tap of m0 + 31.  Stride 1: m0 - HW - 1 .. m0 + 31 + HW + 1.
+  // Stride 2 (40x40 in, 20x20 out): 31 output pixels on are one output row and 11 columns, or two rows on and 9 columns back (a step to the
+  // next row - or into the next image - is 2 HW input pixels): at most 4 HW - 18 input pixels on, + the taps' HW + 1 on either side
+  static constexpr int SPAN = ST == 1 ? 32 + 2 * HW + 2 : 4 * HW - 2 * (HW - 31) + 1 + 2 * HW + 2;
+  static_assert(ST == 1 || (ST == 2 && HW == 40), "stride 2: 40x40 -> 20x20");
   static constexpr int BAND_BYTES = (SPAN + 1) * PITCH * 2;      // + the zero row
   static constexpr int PART_BYTES = SM_NW * 32 * SM_LD * 4;
   static constexpr int LDS_BYTES = BAND_BYTES > PART_BYTES ? BAND_BYTES : PART_BYTES;
 };
 
-// KS 16-channel steps per tap and wave: Cin = 128 KS; HW x HW maps
-template <int KS, int HW>
+// KS 16-channel steps per tap and wave: Cin = 128 KS; HW x HW input maps, stride ST (1 or 2: HW/2 x HW/2 output maps)
+template <int KS, int HW, int ST>
 __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, const f16 *__restrict__ wsm) {
-  using C = SmallCfg<KS, HW>;
+  using C = SmallCfg<KS, HW, ST>;
+  constexpr int HO = HW / ST;
   extern __shared__ __attribute__((aligned(16))) f16 band[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
   const int nct = p.Cout >> 5;
@@ -56,17 +61,22 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
 #pragma unroll
       for (int j = 0; j < KS; ++j) af[t][j] = *reinterpret_cast<const half8 *>(wb + (t * KS + j) * 512);
   }
-  // ---- the pixels the tile's taps touch: input pixels [m0 - HW - 1, m0 + 32 + HW + 1) -> LDS rows 0 .. SPAN - 1; row SPAN = zeros
+  // ---- the pixels the tile's taps touch: ONE contiguous range of input pixels from pb on -> LDS rows 0 .. SPAN - 1; row SPAN = zeros
+  auto in_index = [&](int mm) -> int {                  // flat input pixel under the centre tap of output pixel mm
+    if constexpr (ST == 1) return mm;
+    const int im = mm / (HO * HO), r = mm - im * (HO * HO), yy = r / HO, xx = r - yy * HO;
+    return im * (HW * HW) + (yy * ST) * HW + xx * ST;
+  };
+  const int pb = in_index(m0) - HW - 1, n_in = p.Nimg * HW * HW;
   {
     constexpr int PPR = C::CIN / 8;                     // 16-byte pieces per pixel
     constexpr int NP = C::SPAN * PPR, IT = (NP + SM_NW * 64 - 1) / (SM_NW * 64);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v[IT];
-    const int pb = m0 - HW - 1;
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * (SM_NW * 64), pl = i / PPR, c8 = i - pl * PPR, pix = pb + pl;
-      const bool ok = i < NP && pix >= 0 && pix < p.M;
+      const bool ok = i < NP && pix >= 0 && pix < n_in;
       v[u] = *reinterpret_cast<const u32x4 *>(p.in + (size_t)(ok ? pix : 0) * C::CIN + c8 * 8);
       if (!ok) v[u] = u32x4{0u, 0u, 0u, 0u};
     }
@@ -81,7 +91,8 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
   // ---- K loop: this lane's pixel (operand B) m0 + lr; its k-block of step j: channels cofs + 8 j .. + 8
   const int m = m0 + lr;
   const bool mv = m < p.M;
-  const int rem = m % (HW * HW), y = rem / HW, x = rem - y * HW;
+  const int rem = m % (HO * HO), yo = rem / HO, y = yo * ST, x = (rem - yo * HO) * ST;      // centre tap in the input map
+  const int l0 = in_index(mv ? m : m0) - pb - HW - 1;   // LDS row of this lane's tap (0, 0)
   const int cofs = w * (16 * KS) + lh * (8 * KS);
   floatx16 acc;
 #pragma unroll
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int xx = x + kx - 1;
-      const int row = (yok && xx >= 0 && xx < HW) ? lr + ky * HW + kx : C::SPAN;
+      const int row = (yok && xx >= 0 && xx < HW) ? l0 + ky * HW + kx : C::SPAN;
       const f16 *src = band + row * C::PITCH + cofs;
 #pragma unroll
       for (int j = 0; j < KS; ++j)
@@ -159,9 +170,10 @@ __global__ __launch_bounds__(256) void small_pack_kernel(const f16 *__restrict__
 }  // namespace
 
 void conv_small_kernel_lds(std::vector<KernelLds> &v) {
-  v.push_back({(const void *)conv3x3_small_kernel<1, 40>, SmallCfg<1, 40>::LDS_BYTES});
-  v.push_back({(const void *)conv3x3_small_kernel<2, 40>, SmallCfg<2, 40>::LDS_BYTES});
-  v.push_back({(const void *)conv3x3_small_kernel<4, 20>, SmallCfg<4, 20>::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_small_kernel<1, 40, 1>, SmallCfg<1, 40, 1>::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_small_kernel<2, 40, 1>, SmallCfg<2, 40, 1>::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_small_kernel<4, 20, 1>, SmallCfg<4, 20, 1>::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_small_kernel<2, 40, 2>, SmallCfg<2, 40, 2>::LDS_BYTES});
 }
 
 size_t small_packed_halfs(int Cout, int Cin) { return (size_t)Cout * 9 * Cin; }
@@ -174,17 +186,20 @@ int small_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, 
   return FP_OK;
 }
 
-// The layers this form runs: the 3x3 stride-1 layers of the trunks (128 / 256 channels on 40x40 maps, 512 on 20x20) in launches of at
-// most FP_SMALL_MAX_WG workgroups (default 2 per CU: one and two hypotheses' worth of the largest layer), when the caller holds the
+// The layers this form runs: the 3x3 stride-1 layers of the trunks (128 / 256 channels on 40x40 maps, 512 on 20x20) and the 256 -> 512
+// stride-2 layer (40x40 -> 20x20) in the network passes
+// of one or two hypotheses, and stand-alone launches of at most FP_SMALL_MAX_WG workgroups (default 2 per CU), when the caller holds the
 // packed weights (ConvArgs::wsm).  FP_SMALL=0: off (A/B timing).
 bool conv_small_shape(const ConvArgs &a, int num_cu) {
   static const int on = getenv("FP_SMALL") ? atoi(getenv("FP_SMALL")) : 1;
   static const int max_wg = getenv("FP_SMALL_MAX_WG") ? atoi(getenv("FP_SMALL_MAX_WG")) : 0;
   if (!on) return false;
-  if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H == a.W && a.Ho == a.H && a.Wo == a.W && a.out_mode == 0 &&
-        ((a.W == 40 && (a.Cin == 128 || a.Cin == 256)) || (a.W == 20 && a.Cin == 512)) && a.Cout % 32 == 0 && a.Kpad == 9 * a.Cin &&
+  const bool s1 = a.stride == 1 && a.Ho == a.H && a.Wo == a.W && ((a.W == 40 && (a.Cin == 128 || a.Cin == 256)) || (a.W == 20 && a.Cin == 512));
+  const bool s2 = a.stride == 2 && a.W == 40 && a.Ho == 20 && a.Wo == 20 && a.Cin == 256;       // the 256 -> 512 stride-2 layer between the two halves of encodeAB
+  if (!(a.KH == 3 && a.KW == 3 && a.pad == 1 && a.H == a.W && a.out_mode == 0 && (s1 || s2) && a.Cout % 32 == 0 && a.Kpad == 9 * a.Cin &&
         a.out_ld % 4 == 0 && a.coff_hi % 4 == 0 && a.M > 0))
     return false;
+  if (a.hyp > 0 && max_wg == 0) return a.hyp <= 2;           // inside a network pass: by its hypotheses, whatever the launch's share of them
   const long long wgs = (long long)((a.M + 31) / 32) * (a.Cout / 32);
   return wgs <= (max_wg > 0 ? max_wg : 2 * num_cu);
 }
@@ -194,10 +209,13 @@ int launch_conv_small(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   FP_REQUIRE(conv_small_use(a, ctx->num_cu), "conv3x3 small: unsupported layer");
   FP_REQUIRE((double)a.M * a.Cin * 2.0 < 2147483648.0, "conv3x3 small: input tensor too large");
   const int grid = ((a.M + 31) / 32) * (a.Cout / 32);
-  constexpr int l1 = SmallCfg<1, 40>::LDS_BYTES, l2 = SmallCfg<2, 40>::LDS_BYTES, l4 = SmallCfg<4, 20>::LDS_BYTES;
-  if (a.Cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<1, 40>), dim3(grid), dim3(SM_NW * 64), l1, s, a, a.wsm);
-  else if (a.Cin == 256) hipLaunchKernelGGL((conv3x3_small_kernel<2, 40>), dim3(grid), dim3(SM_NW * 64), l2, s, a, a.wsm);
-  else hipLaunchKernelGGL((conv3x3_small_kernel<4, 20>), dim3(grid), dim3(SM_NW * 64), l4, s, a, a.wsm);
+  constexpr int l1 = SmallCfg<1, 40, 1>::LDS_BYTES, l2 = SmallCfg<2, 40, 1>::LDS_BYTES, l4 = SmallCfg<4, 20, 1>::LDS_BYTES, l2s = SmallCfg<2, 40, 2>::LDS_BYTES;
+  static_assert(l2s <= 160 * 1024 - 1024, "stride-2 band fits LDS");
+  const dim3 g(grid), b(SM_NW * 64);
+  if (a.stride == 2) hipLaunchKernelGGL((conv3x3_small_kernel<2, 40, 2>), g, b, l2s, s, a, a.wsm);
+  else if (a.Cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<1, 40, 1>), g, b, l1, s, a, a.wsm);
+  else if (a.Cin == 256) hipLaunchKernelGGL((conv3x3_small_kernel<2, 40, 1>), g, b, l2, s, a, a.wsm);
+  else hipLaunchKernelGGL((conv3x3_small_kernel<4, 20, 1>), g, b, l4, s, a, a.wsm);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }

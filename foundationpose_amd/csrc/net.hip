@@ -158,7 +158,7 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
     FP_TRY(s2_pack_weights(out->w, Cout, CinP, Kpad, out->wpk, nullptr, stride == 1 ? 2 : 0, stride == 1 ? 1 : 0));      // (conv_s1b.hip: 64 couts per wave group)
     FP_CHECK_HIP(hipStreamSynchronize(nullptr));
   }
-  if (K == 3 && stride == 1 && (CinP == 128 || CinP == 256 || CinP == 512) && Cout % 32 == 0 && Kpad == 9 * CinP) {
+  if (K == 3 && ((stride == 1 && (CinP == 128 || CinP == 256 || CinP == 512)) || (stride == 2 && CinP == 256)) && Cout % 32 == 0 && Kpad == 9 * CinP) {
     void *pk = nullptr;
     FP_CHECK_HIP(hipMalloc(&pk, small_packed_halfs(Cout, CinP) * sizeof(f16)));
     net->allocs.push_back(pk);
@@ -368,7 +368,7 @@ struct Conv2dCall {
   int tokens = 400;
 };
 
-int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scratch = nullptr) {
+int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scratch = nullptr, int hyp = 0) {
   ConvArgs a;
   const ConvW &w = *c.cw;
   a.in = c.in;
@@ -376,6 +376,7 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
   a.wpk = w.wpk;
   a.wwino = w.wwino;
   a.wsm = w.wsm;
+  a.hyp = hyp;
   a.bias = w.bias;
   a.res = c.res;
   a.post_add = c.post_add;
@@ -451,42 +452,42 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
       hipStream_t st = h == 0 ? s : ab->stream_for(0);
       float *skh = sk ? sk + (size_t)h * 4 * N * 1600 * 128 : nullptr;
       const size_t o80 = (size_t)h * N * 80 * 80 * 64, o40 = (size_t)h * N * 1600 * 128;
-      c = Conv2dCall{h == 0 ? xA : xB, N, 160, 160, &t[0]}; c.out = a0 + o80; FP_TRY(run_conv(ctx, c, st, skh));
-      c = Conv2dCall{a0 + o80, N, 80, 80, &t[1]}; c.out = a1 + o40; FP_TRY(run_conv(ctx, c, st, skh));
-      c = Conv2dCall{a1 + o40, N, 40, 40, &t[2]}; c.out = tA + o40; FP_TRY(run_conv(ctx, c, st, skh));
-      c = Conv2dCall{tA + o40, N, 40, 40, &t[3]}; c.res = a1 + o40; c.out = a2 + o40; FP_TRY(run_conv(ctx, c, st, skh));
-      c = Conv2dCall{a2 + o40, N, 40, 40, &t[4]}; c.out = tA + o40; FP_TRY(run_conv(ctx, c, st, skh));
+      c = Conv2dCall{h == 0 ? xA : xB, N, 160, 160, &t[0]}; c.out = a0 + o80; FP_TRY(run_conv(ctx, c, st, skh, N));
+      c = Conv2dCall{a0 + o80, N, 80, 80, &t[1]}; c.out = a1 + o40; FP_TRY(run_conv(ctx, c, st, skh, N));
+      c = Conv2dCall{a1 + o40, N, 40, 40, &t[2]}; c.out = tA + o40; FP_TRY(run_conv(ctx, c, st, skh, N));
+      c = Conv2dCall{tA + o40, N, 40, 40, &t[3]}; c.res = a1 + o40; c.out = a2 + o40; FP_TRY(run_conv(ctx, c, st, skh, N));
+      c = Conv2dCall{a2 + o40, N, 40, 40, &t[4]}; c.out = tA + o40; FP_TRY(run_conv(ctx, c, st, skh, N));
       // the channel concat cat((a,b),1): side A -> channels [0,128), side B -> [128,256) of the same rows
       c = Conv2dCall{tA + o40, N, 40, 40, &t[5]}; c.res = a2 + o40; c.out = ab0; c.out_ld = 256;
       if (h == 1) c.split_m = 0, c.coff_hi = 128;
-      FP_TRY(run_conv(ctx, c, st, skh));
+      FP_TRY(run_conv(ctx, c, st, skh, N));
     }
     FP_TRY(ab->join());
   } else {
   // encodeA / encoderA on cat([A,B],0)
   // (A and B halves of the net tensor may come from different places when the batch is processed in chunks)
-  c = Conv2dCall{xA, N, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{xB, N, 160, 160, &t[0]}; c.out = a0 + (size_t)N * 80 * 80 * 64; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{a0, (int)n2, 80, 80, &t[1]}; c.out = a1; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{a1, (int)n2, 40, 40, &t[2]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{tA, (int)n2, 40, 40, &t[3]}; c.res = a1; c.out = a2; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{a2, (int)n2, 40, 40, &t[4]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{xA, N, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{xB, N, 160, 160, &t[0]}; c.out = a0 + (size_t)N * 80 * 80 * 64; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{a0, (int)n2, 80, 80, &t[1]}; c.out = a1; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{a1, (int)n2, 40, 40, &t[2]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{tA, (int)n2, 40, 40, &t[3]}; c.res = a1; c.out = a2; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{a2, (int)n2, 40, 40, &t[4]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, sk, N));
   // last conv of encodeA writes the channel-concat cat((a,b),1) directly: image n<N -> channels [0,128), n>=N -> [128,256)
   c = Conv2dCall{tA, (int)n2, 40, 40, &t[5]}; c.res = a2; c.out = ab0; c.out_ld = 256; c.split_m = N * 1600; c.coff_hi = 128;
-  FP_TRY(run_conv(ctx, c, s, sk));
+  FP_TRY(run_conv(ctx, c, s, sk, N));
   }
   // encodeAB
-  c = Conv2dCall{ab0, N, 40, 40, &t[6]}; c.out = tB; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{tB, N, 40, 40, &t[7]}; c.res = ab0; c.out = ab1; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{ab1, N, 40, 40, &t[8]}; c.out = tB; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{tB, N, 40, 40, &t[9]}; c.res = ab1; c.out = ab0; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{ab0, N, 40, 40, &t[10]}; c.out = c0; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{c0, N, 20, 20, &t[11]}; c.out = tC; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{tC, N, 20, 20, &t[12]}; c.res = c0; c.out = c1; FP_TRY(run_conv(ctx, c, s, sk));
-  c = Conv2dCall{c1, N, 20, 20, &t[13]}; c.out = tC; FP_TRY(run_conv(ctx, c, s, sk));
+  c = Conv2dCall{ab0, N, 40, 40, &t[6]}; c.out = tB; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{tB, N, 40, 40, &t[7]}; c.res = ab0; c.out = ab1; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{ab1, N, 40, 40, &t[8]}; c.out = tB; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{tB, N, 40, 40, &t[9]}; c.res = ab1; c.out = ab0; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{ab0, N, 40, 40, &t[10]}; c.out = c0; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{c0, N, 20, 20, &t[11]}; c.out = tC; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{tC, N, 20, 20, &t[12]}; c.res = c0; c.out = c1; FP_TRY(run_conv(ctx, c, s, sk, N));
+  c = Conv2dCall{c1, N, 20, 20, &t[13]}; c.out = tC; FP_TRY(run_conv(ctx, c, s, sk, N));
   // reshape(bs,C,-1).permute(0,2,1) is the NHWC tensor itself; pos_embed.pe added in the epilogue
   c = Conv2dCall{tC, N, 20, 20, &t[14]}; c.res = c1; c.out = tok; c.post_add = net->pe; c.post_period = 400;
-  FP_TRY(run_conv(ctx, c, s, sk));
+  FP_TRY(run_conv(ctx, c, s, sk, N));
   *tokens_out = tok;
   return FP_OK;
 }

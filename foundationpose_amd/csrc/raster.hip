@@ -328,14 +328,24 @@ __global__ __launch_bounds__(RB_THREADS) void classify_faces_kernel(RenderArgs a
 }
 
 // MODE 0: the API form (fp32 channels-last maps), 1: the fused network tensor, 2: dr.rasterize's own output only (u, v, z/w, triangle id + 1: parity tests)
-template <int MODE>
+// SOLO: the whole render of a hypothesis' strip in THIS launch - for one or two hypotheses (a tracking frame), where the vertex pass,
+// the classification and this kernel are three dependent launches of a few workgroups each (4.5 + 7.8 + 31 us and two 5-us gaps at
+// one hypothesis, 37 us of it with nothing to draw).  Every strip's workgroup transforms all vertices itself (A records straight
+// into LDS), files the faces that touch ITS strip into lists in LDS (16-bit entries; the same tests and size classes as
+// classify_faces_kernel), and takes the B / C records of the few vertices it needs from vertex_records() directly: the same
+// functions on the same inputs, and a z-buffer of (depth, face) keys under atomicMin does not depend on the order of the lists,
+// so the images are bit-identical to the three-launch form (test_render_solo_equals_three_launches).
+template <int MODE, bool SOLO>
 __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int strip_rows, int n_strips, const int4 *__restrict__ recC,
                                                             const float4 *__restrict__ recB, const uint2 *__restrict__ recA, const int *__restrict__ count,
                                                             const unsigned *__restrict__ listA, const unsigned *__restrict__ listB, int lds_verts, int G, int Fg) {
-  // dynamic LDS: the strip (8 B per pixel), the queue of its covered pixels (2 B per pixel), then (lds_verts) the hypothesis' A records
+  // dynamic LDS: the strip (8 B per pixel), the queue of its covered pixels (2 B per pixel), then (lds_verts) the hypothesis' A records,
+  // then (SOLO) the strip's two face lists, 2 B per face each
   extern __shared__ __attribute__((aligned(16))) unsigned long long zbuf[];
   __shared__ float sM[16];
+  __shared__ float sP[12];
   __shared__ int covn;
+  __shared__ int scnt[3];
   const int L = xcd_remap(blockIdx.x, gridDim.x);          // the strips of one hypothesis share an XCD's L2
   const int b = L / n_strips, strip = L % n_strips;
   const int Ho = a.Ho, Wo = a.Wo;
@@ -347,14 +357,57 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   const uint2 *gA = recA + (size_t)b * m.V;
   unsigned short *covq = reinterpret_cast<unsigned short *>(zbuf + (size_t)strip_rows * Wo);
   uint2 *ldsA = reinterpret_cast<uint2 *>(reinterpret_cast<char *>(covq) + ((((size_t)strip_rows * Wo * 2) + 15) & ~(size_t)15));
+  unsigned short *soloA = reinterpret_cast<unsigned short *>(ldsA + ((m.V + 1) & ~1));
+  unsigned short *soloB = soloA + ((m.F + 7) & ~7);
 
   if (threadIdx.x == 0) {
     clip_matrix(a, b, pose, sM);
     covn = 0;
+    if constexpr (SOLO) {
+      for (int i = 0; i < 12; ++i) sP[i] = pose[i];
+      scnt[0] = scnt[1] = scnt[2] = 0;
+    }
   }
   for (int i = threadIdx.x; i < npix; i += RB_THREADS) zbuf[i] = ~0ull;
-  if (lds_verts)
+  if constexpr (SOLO) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < m.V; v += RB_THREADS) ldsA[v] = (a.dbg & 64) ? make_uint2(RB_A_NONE, 0u) : vertex_records(a, v, sM, sP).a;
+    __syncthreads();
+    // the faces of this strip (classify_faces_kernel's tests, for one strip): small from the front of soloA, medium from its back
+    // (four faces per thread and round: their index quads are requested together - at one hypothesis a load's latency is all there is to hide)
+    auto file_face = [&](int t, const int4 &f) {
+      const uint2 a0 = ldsA[f.x], a1 = ldsA[f.y], a2 = ldsA[f.z];
+      if (a0.x == RB_A_NONE || a1.x == RB_A_NONE || a2.x == RB_A_NONE) {
+        const bool front = (a0.x != RB_A_NONE || __uint_as_float(a0.y) > 0.f) || (a1.x != RB_A_NONE || __uint_as_float(a1.y) > 0.f) ||
+                           (a2.x != RB_A_NONE || __uint_as_float(a2.y) > 0.f);
+        if (front) soloB[atomicAdd(&scnt[2], 1)] = (unsigned short)t;
+        return;
+      }
+      const int X0 = (short)(a0.x & 0xffffu), Y0 = (int)a0.x >> 16, X1 = (short)(a1.x & 0xffffu), Y1 = (int)a1.x >> 16,
+                X2 = (short)(a2.x & 0xffffu), Y2 = (int)a2.x >> 16;
+      if ((X1 - X0) * (Y2 - Y0) - (X2 - X0) * (Y1 - Y0) == 0) return;
+      const int xmin = min(X0, min(X1, X2)), xmax = max(X0, max(X1, X2));
+      const int ymin = min(Y0, min(Y1, Y2)), ymax = max(Y0, max(Y1, Y2));
+      const int ia = max((xmin - 8 + 15) >> 4, 0), ib = min((xmax - 8) >> 4, Wo - 1);
+      const int ja = max((ymin - 8 + 15) >> 4, row0), jb = min((ymax - 8) >> 4, row1 - 1);
+      if (ia > ib || ja > jb) return;
+      const int nc = (ib - ia + 1) * (jb - ja + 1);
+      if (nc <= RB_SMALL) soloA[atomicAdd(&scnt[0], 1)] = (unsigned short)t;
+      else if (nc <= RB_MEDIUM) soloA[m.F - 1 - atomicAdd(&scnt[1], 1)] = (unsigned short)t;
+      else soloB[atomicAdd(&scnt[2], 1)] = (unsigned short)t;
+    };
+    const int F_do = (a.dbg & 32) ? 0 : m.F;
+    for (int t0 = threadIdx.x; t0 < F_do; t0 += 4 * RB_THREADS) {
+      int4 fq[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fq[u] = m.faces4[min(t0 + u * RB_THREADS, m.F - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (t0 + u * RB_THREADS < F_do) file_face(t0 + u * RB_THREADS, fq[u]);
+    }
+  } else if (lds_verts) {
     for (int i = threadIdx.x; i < m.V; i += RB_THREADS) ldsA[i] = gA[i];
+  }
   __syncthreads();
 
   // (the clip matrix stays in LDS: only triangles that straddle the camera plane read it)
@@ -362,7 +415,11 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   const float hw = 0.5f * (float)Wo, hh = 0.5f * (float)Ho;
   const int4 *vc = recC + (size_t)b * m.V;
   const float4 *vbB = recB + 2 * (size_t)b * m.V;
-  auto getA = [&](int i) -> uint2 { return lds_verts ? ldsA[i] : gA[i]; };
+  auto getA = [&](int i) -> uint2 { return (SOLO || lds_verts) ? ldsA[i] : gA[i]; };
+  auto getC = [&](int i) -> int4 {
+    if constexpr (SOLO) return vertex_records(a, i, sM, sP).c;
+    else return vc[i];
+  };
   auto unpack = [](const int4 &q) -> Vtx {      // record C: exactly xform_vertex's values
     Vtx o;
     o.X = q.x;
@@ -373,10 +430,13 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     return o;
   };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if constexpr (SOLO) G = 1, Fg = m.F;
   for (int grp = 0; grp < G; ++grp) {             // the face ranges the classification was cut into (one from 64 hypotheses on)
-  const int *cnt = count + (((size_t)b * n_strips + strip) * G + grp) * 4;
+  const int *cnt = SOLO ? scnt : count + (((size_t)b * n_strips + strip) * G + grp) * 4;
   const int n_small = (a.dbg & 4) ? 0 : cnt[0], n_med = (a.dbg & 4) ? 0 : cnt[1], n_b = (a.dbg & 20) ? 0 : cnt[2];
   const unsigned *lA = listA + ((size_t)b * n_strips + strip) * G * Fg + (size_t)grp * Fg, *lB = listB + ((size_t)b * n_strips + strip) * G * Fg + (size_t)grp * Fg;
+  auto entryA = [&](int i) -> int { return SOLO ? (int)soloA[i] : (int)lA[i]; };
+  auto entryB = [&](int i) -> int { return SOLO ? (int)soloB[i] : (int)(lB[i] & ~RB_SLOW); };
 
   // ---- pass 1a, per lane: the small and medium triangles of this strip, 32-bit edge functions.  |X|,|Y| < 2^14 -> differences
   // < 2^15, products < 2^30, sums < 2^31: the same integers as the 64-bit form below, so coverage, barycentrics and depth keys
@@ -384,7 +444,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
   // entry's index quad is requested one iteration ahead.
   {
     const int n_a = n_small + n_med;
-    auto entry = [&](int e) -> int { return (int)(e < n_small ? lA[e] : lA[Fg - 1 - (e - n_small)]); };
+    auto entry = [&](int e) -> int { return e < n_small ? entryA(e) : entryA(Fg - 1 - (e - n_small)); };
     int t_n = 0;
     int4 f_n = make_int4(0, 0, 0, 0);
     if ((int)threadIdx.x < n_a) {
@@ -445,9 +505,9 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
     int my_t = 0;
     int4 my_f = make_int4(0, 0, 0, 0), my_c0 = my_f, my_c1 = my_f, my_c2 = my_f;
     if (lane < CHB && base + lane < n_b) {
-      my_t = (int)(lB[base + lane] & ~RB_SLOW);
+      my_t = entryB(base + lane);
       my_f = m.faces4[my_t];
-      my_c0 = vc[my_f.x], my_c1 = vc[my_f.y], my_c2 = vc[my_f.z];
+      my_c0 = getC(my_f.x), my_c1 = getC(my_f.y), my_c2 = getC(my_f.z);
     }
     const int cntw = min(CHB, n_b - base);
     for (int q = 0; q < cntw; ++q) {
@@ -600,8 +660,16 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
       int t = (int)(unsigned)(key & 0xffffffffull);
       const int4 f4 = m.faces4[t];
       const int i0 = f4.x, i1 = f4.y, i2 = f4.z;
-      const float4 rb0 = vbB[2 * i0], rb1 = vbB[2 * i1], rb2 = vbB[2 * i2];
-      const float4 rc0 = vbB[2 * i0 + 1], rc1 = vbB[2 * i1 + 1], rc2 = vbB[2 * i2 + 1];
+      float4 rb0, rb1, rb2, rc0, rc1, rc2;
+      [[maybe_unused]] int4 cc0, cc1, cc2;
+      if constexpr (SOLO) {
+        const VtxRecords q0 = vertex_records(a, i0, sM, sP), q1 = vertex_records(a, i1, sM, sP), q2 = vertex_records(a, i2, sM, sP);
+        rb0 = q0.b0, rb1 = q1.b0, rb2 = q2.b0, rc0 = q0.b1, rc1 = q1.b1, rc2 = q2.b1;
+        cc0 = q0.c, cc1 = q1.c, cc2 = q2.c;
+      } else {
+        rb0 = vbB[2 * i0], rb1 = vbB[2 * i1], rb2 = vbB[2 * i2];
+        rc0 = vbB[2 * i0 + 1], rc1 = vbB[2 * i1 + 1], rc2 = vbB[2 * i2 + 1];
+      }
       const uint2 a0 = getA(i0), a1 = getA(i1), a2 = getA(i2);
       float fa, b0, b1, b2;
       float u, v, w2;
@@ -622,7 +690,7 @@ __global__ __launch_bounds__(RB_THREADS) void render_kernel(RenderArgs a, int st
         u = q0 / qs, v = q1 / qs, w2 = (1.f - u) - v;
         if (RAST) r4[2] = fmaf(b2, __uint_as_float(a2.y), fmaf(b1, __uint_as_float(a1.y), b0 * __uint_as_float(a0.y)));
       } else {
-        const Vtx v0 = unpack(vc[i0]), v1 = unpack(vc[i1]), v2 = unpack(vc[i2]);
+        const Vtx v0 = unpack(SOLO ? cc0 : vc[i0]), v1 = unpack(SOLO ? cc1 : vc[i1]), v2 = unpack(SOLO ? cc2 : vc[i2]);
         if (!(v0.ok && v1.ok && v2.ok)) {         // straddles the camera plane: weights from the homogeneous edge functions
           float c[3][4];
           const int id3[3] = {i0, i1, i2};
@@ -744,15 +812,24 @@ RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu) {
   p.count_bytes = ((size_t)N * p.S * p.G * 16 + 255) & ~(size_t)255;
   p.list_bytes = ((size_t)N * p.S * p.G * p.Fg * 4 + 255) & ~(size_t)255;
   p.total = p.c_bytes + p.b_bytes + p.a_bytes + p.count_bytes + 2 * p.list_bytes;
+  // one or two hypotheses (a tracking frame): vertex pass, classification and triangle pass as ONE launch (render_kernel<.., true>) when a
+  // strip, the A records and the strip's two 16-bit face lists fit a workgroup's LDS.  FP_RENDER_SOLO = largest batch that takes it (0: off).
+  static const int solo_max = getenv("FP_RENDER_SOLO") ? atoi(getenv("FP_RENDER_SOLO")) : 2;
+  p.solo_lds = (((size_t)p.strip_rows * Wo * 8 + ((((size_t)p.strip_rows * Wo * 2) + 15) & ~(size_t)15) + (size_t)((V + 1) & ~1) * 8 + 15) & ~(size_t)15) +
+               2 * (size_t)((F + 7) & ~7) * 2;
+  p.solo = (N <= solo_max && p.lds_verts && F <= 65535 && p.solo_lds <= budget) ? 1 : 0;
   return p;
 }
 
 void raster_kernel_lds(std::vector<KernelLds> &v) {
   v.push_back({(const void *)classify_faces_kernel<true>, 64 * 1024});
   v.push_back({(const void *)classify_faces_kernel<false>, 64 * 1024});
-  v.push_back({(const void *)render_kernel<1>, 148 * 1024});        // the largest strip
-  v.push_back({(const void *)render_kernel<0>, 148 * 1024});
-  v.push_back({(const void *)render_kernel<2>, 148 * 1024});
+  v.push_back({(const void *)render_kernel<1, false>, 148 * 1024});        // the largest strip
+  v.push_back({(const void *)render_kernel<0, false>, 148 * 1024});
+  v.push_back({(const void *)render_kernel<2, false>, 148 * 1024});
+  v.push_back({(const void *)render_kernel<1, true>, 148 * 1024});
+  v.push_back({(const void *)render_kernel<0, true>, 148 * 1024});
+  v.push_back({(const void *)render_kernel<2, true>, 148 * 1024});
 }
 
 int render_chunk(int N, int V, int F, int Ho, int Wo, int num_cu) {
@@ -791,7 +868,9 @@ static int launch_render_one(fp_ctx *ctx, const RenderArgs &a_in, int plan_n, hi
   static const bool two_launches = getenv("FP_RENDER_PREPASS2") != nullptr;       // A/B knob: vertex pre-pass and classification as two launches (identical images)
   // fused where one workgroup per hypothesis classifies (G == 1: from 64 hypotheses on): 220 -> 210 us at 252 hypotheses, 144 -> 136 at 126; with
   // the faces of a hypothesis cut into G ranges every range's workgroup would redo the vertex pass (32 hypotheses: 70 -> 73 us, 1: 32 -> 34)
-  if (pl.lds_verts && pl.G == 1 && !two_launches) {
+  if (pl.solo) {
+    // (nothing in front of the strip kernel)
+  } else if (pl.lds_verts && pl.G == 1 && !two_launches) {
     hipLaunchKernelGGL(classify_faces_kernel<true>, dim3(a.N, pl.G), dim3(RB_THREADS), pl.a_lds, s, a, recA, recC, recB, count, listA, listB, pl.S,
                        pl.strip_rows, pl.lds_verts, pl.G, pl.Fg);
   } else {
@@ -801,16 +880,16 @@ static int launch_render_one(fp_ctx *ctx, const RenderArgs &a_in, int plan_n, hi
   }
   FP_CHECK_HIP(hipGetLastError());
   auto go = [&](auto kern) -> int {
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * pl.S)), dim3(RB_THREADS), pl.lds_bytes, s, a, pl.strip_rows, pl.S, (const int4 *)recC,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * pl.S)), dim3(RB_THREADS), pl.solo ? pl.solo_lds : pl.lds_bytes, s, a, pl.strip_rows, pl.S, (const int4 *)recC,
                        (const float4 *)recB, (const uint2 *)recA, (const int *)count, (const unsigned *)listA, (const unsigned *)listB, pl.lds_verts, pl.G,
                        pl.Fg);
     return FP_OK;
   };
   if (a.net_out) {
-    FP_TRY(go(render_kernel<1>));
+    FP_TRY(pl.solo ? go(render_kernel<1, true>) : go(render_kernel<1, false>));
   } else {
-    if (a.color || a.depth || a.normal || a.xyz) FP_TRY(go(render_kernel<0>));
-    if (a.rast) FP_TRY(go(render_kernel<2>));        // (a second pass over the same lists: the parity tests' output)
+    if (a.color || a.depth || a.normal || a.xyz) FP_TRY(pl.solo ? go(render_kernel<0, true>) : go(render_kernel<0, false>));
+    if (a.rast) FP_TRY(pl.solo ? go(render_kernel<2, true>) : go(render_kernel<2, false>));        // (a second pass over the same lists: the parity tests' output)
   }
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;

@@ -224,7 +224,7 @@ class FoundationPose:
               host=torch.empty((H * W * 4 + n_rgb,), dtype=torch.uint8).pin_memory(),
               depth_f=torch.empty((H, W), dtype=torch.float, device=dev), xyz=torch.empty((H, W, 3), dtype=torch.float, device=dev),
               rgb_f=torch.empty((H, W, 3), dtype=torch.float, device=dev) if is_u8 else None,
-              pose=torch.eye(4, dtype=torch.float, device=dev), pose_of_mesh=torch.eye(4, dtype=torch.float, device=dev),
+              pose=torch.eye(4, dtype=torch.float, device=dev), pose_of_mesh=torch.eye(4, dtype=torch.float).pin_memory(),
               Kd=np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(3, 3)), cfg=self.refiner._c_cfg(), holds_pose=None, graph=None)
     a = _lib.FpTrackArgs()
     a.struct_size = ctypes.sizeof(a)
@@ -250,7 +250,7 @@ class FoundationPose:
     return ws
 
   def _run_frame(self, rgb, depth, K, iteration, n_hyp, sigmas):
-    """One tracking frame: upload (ONE copy), fp_track_frame (eager, or the replay of its captured hipGraph), the 4x4 result back.
+    """One tracking frame: upload (ONE copy), fp_track_frame (eager, or the replay of its captured hipGraph), the 4x4 result read from pinned host memory.
     Returns (pose_of_mesh as a HOST (4,4) float32 array - what track_one returns -, workspace).  Contract: `self.pose_last` and, in the
     multi-hypothesis mode, `self.poses` / `self.scores` / `self.best_id` are VIEWS of the mode's static buffers, overwritten by the
     next frame of the same mode; clone them to keep them."""
@@ -309,7 +309,10 @@ class FoundationPose:
     else:
       ctx.reserve(max(64, n_hyp))
       check(lib().fp_track_frame(ctx.handle, ctypes.byref(ws['args']), stream_ptr(ws['pose'].device)))
-    out = ws['pose_of_mesh'].cpu().numpy().reshape(4, 4)      # the frame's one device-to-host copy (synchronises)
+    # the result lands in pinned host memory, written there by the frame's last launch (the device addresses it directly): no
+    # device-to-host copy is enqueued, the frame ends with one wait for the stream
+    st.synchronize()
+    out = ws['pose_of_mesh'].numpy().copy()
     return out, ws
 
   def track_one(self, rgb, depth, K, iteration, extra={}):

@@ -239,7 +239,8 @@ typedef struct fp_track_args {
   const float *d_perturb;          /* n_hyp*16 rigid perturbations, the first the identity; NULL when n_hyp == 1 */
   float model_center[3];           /* get_tf_to_centered_mesh() = translation by -model_center (src/estimater.py:82-86) */
   float *d_pose;                   /* 16: in = the previous frame's pose (centred mesh), out = this frame's */
-  float *d_pose_of_mesh;           /* 16 out: d_pose @ get_tf_to_centered_mesh(), what track_one returns */
+  float *d_pose_of_mesh;           /* 16 out: d_pose @ get_tf_to_centered_mesh(), what track_one returns; device memory, or pinned host memory
+                                      (hipHostMalloc: the last launch writes it there and the caller only waits for the stream) */
   float *d_poses, *d_scores;       /* n_hyp > 1: the refined hypotheses (n_hyp*16) and their scores (n_hyp) */
   int32_t *d_best;                 /* n_hyp > 1: index of the winner */
   float *d_depth_f, *d_xyz, *d_rgb_f; /* workspace: filtered depth H*W, xyz_map H*W*3, float colours H*W*3 (uint8 frames only) */

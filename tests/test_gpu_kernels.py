@@ -147,6 +147,43 @@ def test_render_full_frame_and_edge_cases(sc, fp):
                               context='metal', glctx=None)
 
 
+def test_render_solo_equals_three_launches(sc, fp):
+  """One or two hypotheses render in ONE launch (raster.hip render_kernel<.., true>: vertex pass, per-strip classification into LDS and
+  triangle pass together - a tracking frame's rasteriser); larger batches in three.  Same functions on the same inputs and an
+  order-independent z-buffer: every output of a hypothesis rendered alone or in a pair equals its slice of a batch of 8, bit for bit -
+  the API's maps, dr.rasterize's own output and the fused fp16 network tensor; also for a pose through the camera plane."""
+  from oracle import geometry as G
+  from foundationpose_amd._lib import check, k_ptr, lib, ptr, stream_ptr
+  poses = util.hypotheses(sc, 8, jitter_seed=3)
+  poses[5, :3, 3] = [0.01, -0.02, 0.05]              # through the camera plane: homogeneous rasterisation, list B only
+  tf = G.compute_crop_window_tf_batch(torch.from_numpy(poses), sc['K'], 1.2, (160, 160), sc['diameter'])
+  bbox = G.crop_bbox2d_ori(tf, (160, 160)).cuda().contiguous()
+  bbox[5] = torch.tensor([200.0, 150.0, 440.0, 390.0])
+  mt = util.to_dev(sc['mt'])
+  dposes = torch.from_numpy(poses).cuda()
+  ctx, dm = fp['ctx'], fp['L'].device_mesh(fp['ctx'], mt)
+  Kd, Kp = k_ptr(sc['K'])
+
+  def api(sel):
+    e = {'rast': None}
+    c, d, n = fp['U'].nvdiffrast_render(K=sc['K'], H=480, W=640, ob_in_cams=dposes[sel], mesh_tensors=mt, bbox2d=bbox[sel], output_size=(160, 160),
+                                        get_normal=True, use_light=True, extra=e)
+    return c, d, n, e['xyz_map'], e['rast']
+
+  def net(sel):
+    p, bb = dposes[sel].contiguous(), bbox[sel].contiguous()
+    out = torch.zeros((len(p), 160, 160, 8), dtype=torch.float16, device='cuda')
+    check(lib().fp_render_net(ctx.handle, dm.handle, ptr(p), len(p), Kp, 480, 640, ptr(bb), 160, 160, sc['diameter'], 1, 0.001, ptr(out), stream_ptr()))
+    return (out,)
+  for fn in (api, net):
+    whole = fn(slice(0, 8))
+    assert float((whole[0] != 0).float().mean()) > 0.05
+    for sel in (slice(0, 1), slice(5, 6), slice(6, 8), slice(4, 6)):
+      part = fn(sel)
+      for k, (w, q) in enumerate(zip(whole, part)):
+        assert torch.equal(w[sel], q), f'{fn.__name__} output {k} of hypotheses {sel} differs between the one-launch and the three-launch form'
+
+
 def _net_tensor_to_planar(t, n):
   """fp16 NHWC8 net tensor -> (n,6,160,160) float32"""
   return t.reshape(n, 160, 160, 8)[..., :6].permute(0, 3, 1, 2).float().cpu()
