@@ -76,7 +76,7 @@ def step_local(est, objects, world, rank):
   # rank for every object: each rank of an 8-GPU job handles exactly 252 hypotheses
   sl = [ranges[rotated_shard(o, rank, world)] for o in range(len(objects))]
   refined = est.refiner.predict_multi([dict(rgb=ob['rgb'], xyz_map=ob['xyz'], K=ob['K'], mesh_tensors=est.mesh_tensors,
-                                            mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b])
+                                            mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b], shared_translation=True)      # (as register() does: the rotation grid around ONE guessed centre, build_job)
                                        for ob, (a, b) in zip(objects, sl)], iteration=ITER)
   offs = [0]
   for a, b in sl:

@@ -6,7 +6,7 @@ build command.  torch is used only for device memory and the current HIP stream.
 import ctypes
 import os
 import weakref
-from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int64, c_uint, c_void_p
 
 import numpy as np
 import torch
@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libfoundationpose_amd.so')
 _lib = None
 
+FP_REFINE_SHARED_TRANSLATION = 1      # include/foundationpose_amd.h
 FP_NET_REFINE, FP_NET_SCORE = 0, 1
 
 
@@ -87,6 +88,7 @@ _PROTOS = {
   'fp_pose_update_deepim': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p]),
   'fp_refine_predict': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, POINTER(FpRefineCfg), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_refine_predict_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, POINTER(FpRefineCfg), c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+  'fp_refine_predict_multi_flags': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, POINTER(FpRefineCfg), c_void_p, c_int, c_void_p, c_void_p, c_uint, c_void_p]),
   'fp_score_predict_features_multi': (c_int, [c_void_p, c_void_p, POINTER(FpObjectBatch), c_int, c_double, c_int, c_void_p, c_void_p, c_void_p]),
   'fp_score_predict_features': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_double, c_double, c_int, c_void_p, c_int, c_void_p, c_void_p]),
   'fp_conv3x3_band_f16': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

@@ -571,7 +571,7 @@ struct RefineFinal {
 };
 
 static int refine_predict_impl(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
-                               float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream, const RefineFinal *fin) {
+                               float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream, const RefineFinal *fin, unsigned flags = 0) {
   FP_REQUIRE(ctx && net && cfg && d_poses, "fp_refine_predict_multi: null argument");
   FP_REQUIRE(iteration >= 0, "fp_refine_predict_multi: bad iteration");
   int N = 0;
@@ -580,9 +580,10 @@ static int refine_predict_impl(fp_ctx *ctx, const fp_net *net, const fp_object_b
   hipStream_t s = (hipStream_t)stream;
   const int rot_dim = fp_net_rot_dim(net);
   const size_t rs_total = render_scratch_total(ctx, objs, n_obj);
-  FP_TRY(fp_arena_ensure(ctx, pass_arena_bytes(N, rs_total)));
+  FP_TRY(fp_arena_ensure(ctx, pass_arena_bytes(N, rs_total) + (size_t)n_obj * ((size_t)4 << 20)));
   const size_t mark = ctx->arena.off;
   const size_t img = (size_t)160 * 160 * 8;
+  static const bool no_shared = getenv("FP_NO_SHARED_B") != nullptr;       // A/B knob: ignore FP_REFINE_SHARED_TRANSLATION (identical results)
   auto body = [&]() -> int {
     TAKE(tf, float, (size_t)N * 9);
     TAKE(bbox, float, (size_t)N * 4);
@@ -602,11 +603,27 @@ static int refine_predict_impl(fp_ctx *ctx, const fp_net *net, const fp_object_b
     int first = 0;
     while (first < n_obj && objs[first].n == 0) ++first;
     const bool fused_tail = n_runs == 1 && !tail_split && fp_hyp_chunk(N) == N;
+    // FP_REFINE_SHARED_TRANSLATION: in the FIRST iteration every hypothesis of an object has the crop window of the object's first one, so
+    // side B - the observed crop and its way through encodeA - is ONE image per object: cropped and encoded once on the side stream
+    // (fp_encode_side_b), copied into the B half of the channel concat by run_trunk.  One run of like objects, at most 8 of them, no
+    // hypothesis chunks; otherwise the plain pass runs.
+    int n_live = 0;
+    for (int o = 0; o < n_obj; ++o) n_live += objs[o].n > 0;
+    const bool shared0 = (flags & FP_REFINE_SHARED_TRANSLATION) && !no_shared && n_runs == 1 && n_live <= 8 && fp_hyp_chunk(N) == N;
+    f16 *xB1 = nullptr, *featB = nullptr;
+    if (shared0) {
+      TAKE(xB1_, f16, (size_t)n_live * img);
+      TAKE(featB_, f16, (size_t)n_live * 1600 * 128);
+      xB1 = xB1_, featB = featB_;
+    }
     for (int it = 0; it < iteration; ++it) {
       size_t voff = 0;
       int off = 0, k = 0;
       StreamFanout fo(ctx, s, two_sides ? 1 : n_runs);
       std::unique_ptr<StreamFanout> ab;
+      const bool shared = shared0 && it == 0;
+      SharedB sb;
+      sb.feat = featB, sb.n_groups = 0;
       for (int o = 0; o < n_obj;) {       // per run of like objects: crop windows + render (side A); per object: observed crop (side B)
         int e = o + 1, cnt = objs[o].n;
         while (e < n_obj && same_render_key(objs[o], objs[e])) cnt += objs[e++].n;
@@ -616,18 +633,29 @@ static int refine_predict_impl(fp_ctx *ctx, const fp_net *net, const fp_object_b
           float *p = d_poses + (size_t)off * 16;
           if (!(fused_tail && it > 0))       // (from the second iteration on the previous pass' tail has written the windows)
             FP_TRY(launch_crop_window_tf(p, cnt, ob.K, cfg->crop_ratio, ob.mesh_diameter, 160, 160, tf + (size_t)off * 9, bbox + (size_t)off * 4, so));
-          if (two_sides) ab.reset(new StreamFanout(ctx, s, 2));          // forks behind the crop windows
+          if (two_sides || shared) ab.reset(new StreamFanout(ctx, s, 2));          // forks behind the crop windows
           const size_t rsb = (render_scratch_bytes(cnt, ob.mesh->d.V, ob.mesh->d.F, 160, 160, ctx->num_cu) + 255) & ~(size_t)255;
           int rc = render_net_impl(ctx, ob.mesh, p, cnt, ob.K, ob.H, ob.W, bbox + (size_t)off * 4, 160, 160, ob.mesh_diameter,
                                    cfg->normalize_xyz, 0.001f, net_in + (size_t)off * img, rscratch + voff, rsb, so);
           voff += rsb;
-          hipStream_t sb = ab ? ab->stream_for(0) : so;
+          hipStream_t sb_stream = ab ? ab->stream_for(0) : so;
           for (int q = o; q < e && rc == FP_OK; ++q) {
             const fp_object_batch &oq = objs[q];
             if (oq.n == 0) continue;
-            rc = fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, oq.n, 160, 160, 0,
-                                  oq.mesh_diameter, cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, sb);
+            if (shared) {       // the object's ONE observed crop (window and translation of its first hypothesis = of all of them)
+              sb.start[sb.n_groups] = off;
+              rc = fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, 1, 160, 160, 0,
+                                    oq.mesh_diameter, cfg->normalize_xyz, 1, xB1 + (size_t)sb.n_groups * img, sb_stream);
+              ++sb.n_groups;
+            } else {
+              rc = fp_crop_observed(ctx, oq.d_rgb, oq.d_geom, oq.H, oq.W, oq.K, tf + (size_t)off * 9, d_poses + (size_t)off * 16, oq.n, 160, 160, 0,
+                                    oq.mesh_diameter, cfg->normalize_xyz, 1, net_in + ((size_t)N + off) * img, sb_stream);
+            }
             off += oq.n;
+          }
+          if (shared && rc == FP_OK) {
+            sb.start[sb.n_groups] = off;
+            rc = fp_encode_side_b(ctx, net, xB1, sb.n_groups, N, featB, sb_stream);
           }
           if (rc != FP_OK) {
             if (ab) (void)ab->join();
@@ -656,11 +684,11 @@ static int refine_predict_impl(fp_ctx *ctx, const fp_net *net, const fp_object_b
           t.centered = fin->centered;
           for (int c = 0; c < 3; ++c) t.cneg[c] = fin->cneg[c];
         }
-        FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get(), &t));
+        FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get(), &t, shared ? &sb : nullptr));
         continue;
       }
       FP_REQUIRE(!fin, "refine pass: the centred poses come from the fused tail launch (one run of like objects, FP_TAIL_SPLIT unset)");
-      FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get()));     // ONE network pass for every object (joins `ab`)
+      FP_TRY(fp_refine_forward_ab(ctx, net, net_in, N, tr, ro, s, ab.get(), nullptr, shared ? &sb : nullptr));     // ONE network pass for every object (joins `ab`)
       // pose update: one launch per run of objects with the same translation scale (one launch when they share a mesh)
       off = 0;
       for (int o = 0; o < n_obj;) {
@@ -687,6 +715,12 @@ static int refine_predict_impl(fp_ctx *ctx, const fp_net *net, const fp_object_b
 extern "C" int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
                                        float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream) {
   return refine_predict_impl(ctx, net, objs, n_obj, cfg, d_poses, iteration, d_trans, d_rot, stream, nullptr);
+}
+
+extern "C" int fp_refine_predict_multi_flags(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
+                                             float *d_poses, int iteration, float *d_trans, float *d_rot, unsigned flags, void *stream) {
+  FP_REQUIRE((flags & ~(unsigned)FP_REFINE_SHARED_TRANSLATION) == 0, "fp_refine_predict_multi_flags: unknown flag bits 0x%x", flags);
+  return refine_predict_impl(ctx, net, objs, n_obj, cfg, d_poses, iteration, d_trans, d_rot, stream, nullptr, flags);
 }
 
 extern "C" int fp_refine_predict(fp_ctx *ctx, const fp_net *net, const fp_mesh *mesh, const float *d_rgb, const float *d_xyz_map,

@@ -161,8 +161,18 @@ struct RefineTailArgs;
 int fp_hyp_chunk(int n_total);             // hypotheses per network pass (FP_CHUNK; default: the whole batch)
 // `tail` (optional; pose / window fields filled by the caller, head fields by the forward pass): the heads' token means, the pose update
 // and the next crop windows as ONE launch behind the join of the heads (refine_tail_kernel) instead of two mean_head launches here
+// `sb` (optional): side B of this pass is ONE observed crop per object - every hypothesis of an object has the same crop window (the first
+// iteration of a registration: the rotation grid around one guessed centre, src/estimater.py:126-135) - already encoded by fp_encode_side_b
+// (on ab->stream_for(0) when `ab` is given): encodeA runs on side A only and the objects' features are copied into the B half of the channel
+// concat.  Same kernels on the same inputs as the batch: the tokens are those of the plain pass bit for bit.
+struct SharedB {
+  const f16 *feat;          // [n_groups][40 x 40][128] fp16: encodeA of each object's observed crop
+  int n_groups;
+  int start[9];             // hypothesis at which object g starts; start[n_groups] = N
+};
+int fp_encode_side_b(fp_ctx *ctx, const fp_net *net, const f16 *xB, int n_groups, int hyp, f16 *feat, hipStream_t s);
 int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab,
-                         RefineTailArgs *tail = nullptr);
+                         RefineTailArgs *tail = nullptr, const SharedB *sb = nullptr);
 int fp_score_features_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_feats, hipStream_t s, StreamFanout *ab, int feat_ld = 512,
                          const float *d_poses = nullptr);      // feat_ld / d_poses: [feature | pose] rows of the all-gather (score_tail.hip)
 

@@ -52,16 +52,8 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
   const int nct = p.Cout >> 5;
   const int ct = blockIdx.x % nct, pt = blockIdx.x / nct;
   const int co0 = ct * 32, m0 = pt * 32;
-  // ---- every weight fragment of this wave: 9 KS coalesced 1-KB loads, in flight across the staging of the band
-  half8 af[9][KS];
-  {
-    const f16 *wb = wsm + ((size_t)(ct * SM_NW + w) * 9 * KS) * 512 + lane * 8;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int j = 0; j < KS; ++j) af[t][j] = *reinterpret_cast<const half8 *>(wb + (t * KS + j) * 512);
-  }
   // ---- the pixels the tile's taps touch: ONE contiguous range of input pixels from pb on -> LDS rows 0 .. SPAN - 1; row SPAN = zeros
+  half8 af[9][KS];
   auto in_index = [&](int mm) -> int {                  // flat input pixel under the centre tap of output pixel mm
     if constexpr (ST == 1) return mm;
     const int im = mm / (HO * HO), r = mm - im * (HO * HO), yy = r / HO, xx = r - yy * HO;
@@ -76,9 +68,19 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
       const int i = tid + u * (SM_NW * 64), pl = i / PPR, c8 = i - pl * PPR, pix = pb + pl;
+      // (rows of the range in front of the first image or behind the last hold whatever pixel 0 holds: no tap reads them - a tap outside its
+      // image reads the zero row -, and a select on the loaded value would make the wave wait for the load before it requests the next)
       const bool ok = i < NP && pix >= 0 && pix < n_in;
       v[u] = *reinterpret_cast<const u32x4 *>(p.in + (size_t)(ok ? pix : 0) * C::CIN + c8 * 8);
-      if (!ok) v[u] = u32x4{0u, 0u, 0u, 0u};
+    }
+    // ---- every weight fragment of this wave: 9 KS coalesced 1-KB loads, requested BEHIND the band's loads (which the first MFMA needs
+    // first) and in flight across the band's way through LDS and the barrier; the K loop consumes them in the order they arrive
+    {
+      const f16 *wb = wsm + ((size_t)(ct * SM_NW + w) * 9 * KS) * 512 + lane * 8;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < KS; ++j) af[t][j] = *reinterpret_cast<const half8 *>(wb + (t * KS + j) * 512);
     }
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
@@ -87,7 +89,10 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
     }
     if (tid < PPR) *reinterpret_cast<u32x4 *>(&band[C::SPAN * C::PITCH + tid * 8]) = u32x4{0u, 0u, 0u, 0u};
   }
-  __syncthreads();
+  // the band is in LDS for every wave (a __syncthreads() would also wait for the weight loads: vmcnt(0))
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
   // ---- K loop: this lane's pixel (operand B) m0 + lr; its k-block of step j: channels cofs + 8 j .. + 8
   const int m = m0 + lr;
   const bool mv = m < p.M;

@@ -414,6 +414,18 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
     return FP_ENOMEM;                                                                     \
   }
 
+// ab0[n][p][128 .. 256) = feat[object of hypothesis h0 + n][p][0 .. 128): the B half of cat((a, b), 1) from one encoded crop per object
+__global__ __launch_bounds__(256) void broadcast_side_b_kernel(const f16 *__restrict__ feat, SharedB sb, int h0, int N, f16 *__restrict__ ab0) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;        // one 16-byte piece: 16 per pixel
+  if (i >= (long long)N * 1600 * 16) return;
+  const int n = (int)(i / (1600 * 16)), r = (int)(i - (long long)n * (1600 * 16)), px = r >> 4, c8 = r & 15;
+  int g = 0;
+  while (g + 1 < sb.n_groups && h0 + n >= sb.start[g + 1]) ++g;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  *reinterpret_cast<u32x4 *>(ab0 + ((size_t)n * 1600 + px) * 256 + 128 + c8 * 8) =
+      *reinterpret_cast<const u32x4 *>(feat + ((size_t)g * 1600 + px) * 128 + c8 * 8);
+}
+
 // shared trunk -> tokens (N*400, 512) fp16, positional embedding added.
 // `ab` (optional): the two sides of encodeA as two chains on two streams.  encodeA runs on cat([A, B], 0) with shared weights
 // (refine_network.py:74-78): nothing couples the rendered side A and the observed side B before the channel concat, and in a fused
@@ -421,7 +433,7 @@ int run_conv(fp_ctx *ctx, const Conv2dCall &c, hipStream_t s, float *splitk_scra
 // side B's input is produced on ab->stream_for(0), side A's on `s`; the chains join in front of encodeAB.  Each side's launches are the
 // 2N-image launches cut in two: a pixel's arithmetic does not depend on its batch, so the tokens are those of the single chain bit for bit.
 int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int N, f16 **tokens_out, hipStream_t s, f16 *tok_dst = nullptr,
-              StreamFanout *ab = nullptr) {
+              StreamFanout *ab = nullptr, const SharedB *sb = nullptr, int h0 = 0) {
   const ConvW *t = net->trunk;
   const size_t n2 = (size_t)2 * N;
   TAKE(a0, f16, n2 * 80 * 80 * 64);
@@ -446,7 +458,18 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
     sk = sk_;
   }
   Conv2dCall c;
-  if (ab && ab->fan) {
+  if (sb) {
+    // side A alone; side B = the objects' encoded crops (SharedB)
+    if (ab) FP_TRY(ab->join());                       // (the crops were encoded on the side stream)
+    c = Conv2dCall{xA, N, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s, sk, N));
+    c = Conv2dCall{a0, N, 80, 80, &t[1]}; c.out = a1; FP_TRY(run_conv(ctx, c, s, sk, N));
+    c = Conv2dCall{a1, N, 40, 40, &t[2]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, sk, N));
+    c = Conv2dCall{tA, N, 40, 40, &t[3]}; c.res = a1; c.out = a2; FP_TRY(run_conv(ctx, c, s, sk, N));
+    c = Conv2dCall{a2, N, 40, 40, &t[4]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, sk, N));
+    c = Conv2dCall{tA, N, 40, 40, &t[5]}; c.res = a2; c.out = ab0; c.out_ld = 256; FP_TRY(run_conv(ctx, c, s, sk, N));
+    hipLaunchKernelGGL(broadcast_side_b_kernel, dim3((unsigned)(((long long)N * 1600 * 16 + 255) / 256)), dim3(256), 0, s, sb->feat, *sb, h0, N, ab0);
+    FP_CHECK_HIP(hipGetLastError());
+  } else if (ab && ab->fan) {
     // encodeA / encoderA, one chain per side; side `h` owns images [h N, h N + N) of every buffer (and its own half of the split-K scratch)
     for (int h = 0; h < 2; ++h) {
       hipStream_t st = h == 0 ? s : ab->stream_for(0);
@@ -498,10 +521,11 @@ int run_trunk(fp_ctx *ctx, const fp_net *net, const f16 *xA, const f16 *xB, int 
 // 256 CUs, 3.08 or 6.15 rounds, and the partial last round costs 3 - 8 % of it (as quarter tiles, round 1); with two half-batch launches
 // queued on two streams the workgroups of the other half start on the CUs the last round leaves idle.  Results are those of the single
 // batch bit for bit (a hypothesis' arithmetic does not depend on its batch).
-int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0, int NT, int N, f16 **tokens_out, hipStream_t s, StreamFanout *ab = nullptr) {
+int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0, int NT, int N, f16 **tokens_out, hipStream_t s, StreamFanout *ab = nullptr,
+                          const SharedB *sb = nullptr) {
   static const int n_streams = getenv("FP_TRUNK_STREAMS") ? atoi(getenv("FP_TRUNK_STREAMS")) : 2;
   const size_t img = (size_t)160 * 160 * 8;
-  if (N < fp_trunk_split_min()) return run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, tokens_out, s, nullptr, ab);
+  if (N < fp_trunk_split_min()) return run_trunk(ctx, net, in + s0 * img, in + ((size_t)NT + s0) * img, N, tokens_out, s, nullptr, ab, sb, s0);
   if (ab) FP_TRY(ab->join());          // (a batch that is cut in two by hypotheses keeps both sides of a half on one stream)
   TAKE(tok, f16, (size_t)N * 400 * 512);
   const int n_parts = std::min(n_streams, std::min(fp_ctx::NSIDE, std::max(2, N / 32)));
@@ -510,7 +534,8 @@ int run_trunk_maybe_split(fp_ctx *ctx, const fp_net *net, const f16 *in, int s0,
   int rc = FP_OK;
   for (int k = 0, a0 = 0; k < n_parts && rc == FP_OK; ++k) {
     const int a1 = (int)((long long)N * (k + 1) / n_parts);
-    rc = run_trunk(ctx, net, in + (s0 + a0) * img, in + ((size_t)NT + s0 + a0) * img, a1 - a0, &t, k == 0 ? s : fo.stream_for(k - 1), tok + (size_t)a0 * 400 * 512);
+    rc = run_trunk(ctx, net, in + (s0 + a0) * img, in + ((size_t)NT + s0 + a0) * img, a1 - a0, &t, k == 0 ? s : fo.stream_for(k - 1), tok + (size_t)a0 * 400 * 512,
+                   nullptr, sb, s0 + a0);
     a0 = a1;
   }
   const int rj = fo.join();            // on every path: the caller resets the arena, which the side streams may still be writing
@@ -559,8 +584,27 @@ extern "C" int fp_refine_forward(fp_ctx *ctx, const fp_net *net, const void *d_n
 }
 
 // `ab`: side B of the network input is being produced on ab->stream_for(0), side A on `s` (the fused passes of api.hip): run_trunk
+// encodeA of `n_groups` observed crops (one per object), with the kernels the batch of `hyp` hypotheses takes for these layers (run_conv's
+// `hyp`: the few-image forms are chosen by the pass, not by the launch) -> feat [n_groups][1600][128]
+int fp_encode_side_b(fp_ctx *ctx, const fp_net *net, const f16 *xB, int n_groups, int hyp, f16 *feat, hipStream_t s) {
+  const ConvW *t = net->trunk;
+  const int G = n_groups;
+  TAKE(a0, f16, (size_t)G * 80 * 80 * 64);
+  TAKE(a1, f16, (size_t)G * 1600 * 128);
+  TAKE(tA, f16, (size_t)G * 1600 * 128);
+  TAKE(a2, f16, (size_t)G * 1600 * 128);
+  Conv2dCall c;
+  c = Conv2dCall{xB, G, 160, 160, &t[0]}; c.out = a0; FP_TRY(run_conv(ctx, c, s, nullptr, hyp));
+  c = Conv2dCall{a0, G, 80, 80, &t[1]}; c.out = a1; FP_TRY(run_conv(ctx, c, s, nullptr, hyp));
+  c = Conv2dCall{a1, G, 40, 40, &t[2]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, nullptr, hyp));
+  c = Conv2dCall{tA, G, 40, 40, &t[3]}; c.res = a1; c.out = a2; FP_TRY(run_conv(ctx, c, s, nullptr, hyp));
+  c = Conv2dCall{a2, G, 40, 40, &t[4]}; c.out = tA; FP_TRY(run_conv(ctx, c, s, nullptr, hyp));
+  c = Conv2dCall{tA, G, 40, 40, &t[5]}; c.res = a2; c.out = feat; FP_TRY(run_conv(ctx, c, s, nullptr, hyp));
+  return FP_OK;
+}
+
 int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, int N, float *d_trans, float *d_rot, hipStream_t s, StreamFanout *ab,
-                         RefineTailArgs *tail) {
+                         RefineTailArgs *tail, const SharedB *sb) {
   FP_REQUIRE(ctx && net && d_net_in && d_trans && d_rot, "fp_refine_forward: null argument");
   FP_REQUIRE(net->kind == FP_NET_REFINE, "fp_refine_forward: not a RefineNet");
   FP_REQUIRE(N >= 0, "fp_refine_forward: N<0");
@@ -573,7 +617,7 @@ int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, i
   auto body = [&](int s0, int N) -> int {
     f16 *tok = nullptr;
     const f16 *in = (const f16 *)d_net_in;
-    FP_TRY(run_trunk_maybe_split(ctx, net, in, s0, NT, N, &tok, s, CH == NT ? ab : nullptr));
+    FP_TRY(run_trunk_maybe_split(ctx, net, in, s0, NT, N, &tok, s, CH == NT ? ab : nullptr, sb));
     const int M = N * 400;
     // The translation and rotation heads are independent transformer layers on the same tokens: each gets its own
     // buffers and its own stream, so the tail of one head's kernels overlaps the other's (their launches are 3.08 rounds of

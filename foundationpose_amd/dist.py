@@ -89,7 +89,7 @@ def sharded_refine_and_score(est, K, rgb, depth, xyz_map, poses, iteration, grou
   if b > a:
     refined, _ = est.refiner.predict(mesh=est.mesh, mesh_tensors=est.mesh_tensors, rgb=rgb, depth=depth, K=K,
                                      ob_in_cams=mine, xyz_map=xyz_map, glctx=est.glctx,
-                                     mesh_diameter=est.diameter, iteration=iteration)
+                                     mesh_diameter=est.diameter, iteration=iteration, shared_translation=True)     # (a shard of register's rotation grid: one centre)
     feats = est.scorer.extract_features(rgb, depth, K, refined, mesh=est.mesh, mesh_tensors=est.mesh_tensors, glctx=est.glctx,
                                         mesh_diameter=est.diameter)
   else:

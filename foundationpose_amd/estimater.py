@@ -154,7 +154,8 @@ class FoundationPose:
       return sharded_refine_and_score(self, K, rgb, depth, xyz_map, hyp, iteration)
     shared = dict(mesh=self.mesh, mesh_tensors=self.mesh_tensors, rgb=rgb, depth=depth, K=K, glctx=self.glctx,
                   mesh_diameter=self.diameter, get_vis=self.debug >= 2)
-    refined, vis = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, **shared)
+    # (register's hypotheses are the rotation grid around ONE guessed centre: the refiner encodes the observed crop of its first iteration once)
+    refined, vis = self.refiner.predict(ob_in_cams=hyp, xyz_map=xyz_map, normal_map=None, iteration=iteration, shared_translation=True, **shared)
     if vis is not None:                  # src/estimater.py:216-217 (debug >= 2)
       from .vis import write_png
       write_png(f'{self.debug_dir}/vis_refiner.png', vis)

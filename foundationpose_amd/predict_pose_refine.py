@@ -186,27 +186,42 @@ class PoseRefinePredictor:
                                tn.ctypes.data, c.rot_normalizer, scale, ptr(out), stream_ptr(poseA.device)))
     return out
 
+  @staticmethod
+  def _shares_translation(ob_in_cams, shared_translation):
+    """True when every hypothesis has the translation of the first one, which makes the observed side of the FIRST iteration one crop
+    (FP_REFINE_SHARED_TRANSLATION in include/foundationpose_amd.h).  `shared_translation` True / False: the caller's word (the estimator
+    knows: its hypotheses are a rotation grid around one guessed centre, src/estimater.py:126-135); None: host arrays - what the reference
+    passes - are compared here, device tensors are not (that would be a synchronisation per call)."""
+    if shared_translation is not None:
+      return bool(shared_translation)
+    if torch.is_tensor(ob_in_cams) and ob_in_cams.is_cuda:
+      return False
+    t = np.asarray(ob_in_cams, dtype=np.float32).reshape(-1, 4, 4)[:, :3, 3]
+    return len(t) > 1 and bool((t == t[0]).all())
+
   @torch.inference_mode()
   def predict_multi(self, objects, iteration=5):
     """Several objects in one pass (BASELINE configs[3]; a rank's slices in the sharded job): `objects` is a list of
-    dicts(rgb, xyz_map, K, mesh_tensors, mesh_diameter, ob_in_cams).  Render / crop run per object, RefineNet once on
-    the concatenated hypotheses.  Returns the refined poses concatenated in object order."""
+    dicts(rgb, xyz_map, K, mesh_tensors, mesh_diameter, ob_in_cams [, shared_translation]).  Render / crop run per object, RefineNet once
+    on the concatenated hypotheses.  Returns the refined poses concatenated in object order."""
     arr, poses, keep = _lib.object_batches(self.ctx, objects, 'xyz_map')
     c = self._c_cfg()
     N = len(poses)
     trans = torch.empty((N, 3), device=poses.device, dtype=torch.float)
     rot = torch.empty((N, self.model.rot_dim), device=poses.device, dtype=torch.float)
-    check(lib().fp_refine_predict_multi(self.ctx.handle, self.model.handle, arr, len(objects), byref(c), ptr(poses), int(iteration),
-                                        ptr(trans), ptr(rot), stream_ptr(poses.device)))
+    flags = _lib.FP_REFINE_SHARED_TRANSLATION if all(self._shares_translation(ob['ob_in_cams'], ob.get('shared_translation')) for ob in objects) else 0
+    check(lib().fp_refine_predict_multi_flags(self.ctx.handle, self.model.handle, arr, len(objects), byref(c), ptr(poses), int(iteration),
+                                              ptr(trans), ptr(rot), flags, stream_ptr(poses.device)))
     self.last_trans_update, self.last_rot_update = trans, rot
     return poses
 
   @torch.inference_mode()
   def predict(self, rgb, depth, K, ob_in_cams, xyz_map, normal_map=None, get_vis=False, mesh=None, mesh_tensors=None, glctx=None,
-              mesh_diameter=None, iteration=5):
+              mesh_diameter=None, iteration=5, shared_translation=None):
     '''
     @rgb: np array (H,W,3)
     @ob_in_cams: np array (N,4,4)
+    @shared_translation: see _shares_translation (an extension; the results do not depend on it)
     returns (B_in_cams (N,4,4) float tensor on the device, vis or None)
     '''
     logging.info(f'ob_in_cams:{np.shape(ob_in_cams)}')
@@ -236,8 +251,11 @@ class PoseRefinePredictor:
     trans = torch.empty((N, 3), device=dev, dtype=torch.float)
     rot = torch.empty((N, self.model.rot_dim), device=dev, dtype=torch.float)
     Kd, Kp = k_ptr(K)
-    check(lib().fp_refine_predict(ctx.handle, self.model.handle, dm.handle, ptr(rgb_t), ptr(xyz_t), H, W, Kp, float(mesh_diameter),
-                                  byref(c), ptr(poses), N, int(iteration), ptr(trans), ptr(rot), stream_ptr(dev)))
+    ob = _lib.FpObjectBatch()
+    ob.mesh, ob.d_rgb, ob.d_geom, ob.H, ob.W, ob.K, ob.mesh_diameter, ob.n = dm.handle, rgb_t.data_ptr(), xyz_t.data_ptr(), H, W, Kd.ctypes.data, float(mesh_diameter), N
+    flags = _lib.FP_REFINE_SHARED_TRANSLATION if self._shares_translation(ob_in_cams, shared_translation) else 0
+    check(lib().fp_refine_predict_multi_flags(ctx.handle, self.model.handle, byref(ob), 1, byref(c), ptr(poses), int(iteration), ptr(trans), ptr(rot),
+                                              flags, stream_ptr(dev)))
     self.last_trans_update = trans
     self.last_rot_update = rot
     if get_vis:

@@ -209,6 +209,15 @@ typedef struct {
 } fp_object_batch;
 int fp_refine_predict_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
                             float *d_poses, int iteration, float *d_trans, float *d_rot, void *stream);
+/* The same with flags.  FP_REFINE_SHARED_TRANSLATION: the caller states that, on entry, every hypothesis of an object has the SAME
+ * translation - what FoundationPose.register builds (src/estimater.py:126-135,196-199: the rotation grid around ONE guessed centre).  The
+ * crop window depends on the translation only (src/Utils.py:577-621), so in the first iteration the observed side (predict_pose_refine.py:63,72
+ * and its half of RefineNet.encodeA, refine_network.py:74-78) is one crop per object: it is cropped and encoded once instead of once per
+ * hypothesis, by the same kernels - the refined poses are those of fp_refine_predict_multi bit for bit.  A false statement gives the
+ * hypotheses of an object the first one's observed crop in iteration 1. */
+#define FP_REFINE_SHARED_TRANSLATION 1u
+int fp_refine_predict_multi_flags(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, const fp_refine_cfg *cfg,
+                                  float *d_poses, int iteration, float *d_trans, float *d_rot, unsigned flags, void *stream);
 int fp_score_predict_features_multi(fp_ctx *ctx, const fp_net *net, const fp_object_batch *objs, int n_obj, double crop_ratio,
                                     int normalize_xyz, const float *d_poses, float *d_feats, void *stream);
 

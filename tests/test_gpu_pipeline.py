@@ -471,12 +471,49 @@ def test_to_device_moves_the_predictors(nets_gpu):
   assert est.some_tensor.is_cuda and est.mesh_tensors['pos'].is_cuda
 
 
+def test_shared_translation_first_pass_is_bit_identical():
+  """FP_REFINE_SHARED_TRANSLATION (register's hypotheses: one rotation grid around ONE centre, src/estimater.py:126-135): the observed side of
+  the first iteration is cropped and run through encodeA once per object instead of once per hypothesis.  Same kernels on the same
+  inputs: the refined poses equal those of the plain pass BIT FOR BIT - 2 hypotheses (the few-image kernels), 8 (two chains), 56 and 100
+  (the trunk in two halves), and three objects of 5 + 0 + 7 hypotheses in one pass; a host array is detected, a device tensor is not."""
+  from oracle import geometry as G
+  from foundationpose_amd import synthetic as S
+  from foundationpose_amd.config import REFINE_DEFAULT
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor
+  sc = util.scene(0)
+  r = PoseRefinePredictor(state_dict=S.make_refine_state_dict(0), cfg=REFINE_DEFAULT)
+  depth = G.bilateral_filter_depth(G.erode_depth(sc['depth']))
+  xyz = G.depth2xyzmap(depth, sc['K'])
+  mt = util.to_dev(sc['mt'])
+  kw = dict(rgb=sc['rgb'], depth=depth, K=sc['K'], xyz_map=xyz, mesh_tensors=mt, mesh_diameter=sc['diameter'], iteration=2)
+  assert r._shares_translation(util.hypotheses(sc, 4), None) and not r._shares_translation(util.hypotheses(sc, 4, jitter_seed=1), None)
+  assert not r._shares_translation(torch.from_numpy(util.hypotheses(sc, 4)).cuda(), None)
+  for n in (2, 8, 56, 100):
+    poses = np.ascontiguousarray(np.concatenate([sc['grid']] * 2)[:n].astype(np.float32))
+    poses[:, :3, 3] = util.hypotheses(sc, 1)[0, :3, 3]
+    plain, _ = r.predict(ob_in_cams=poses, shared_translation=False, **kw)
+    once, _ = r.predict(ob_in_cams=poses, shared_translation=True, **kw)
+    auto, _ = r.predict(ob_in_cams=poses, **kw)
+    assert torch.equal(plain, once) and torch.equal(plain, auto), f'{n} hypotheses: {float((plain - once).abs().max()):.2e}'
+    assert float((plain.cpu() - torch.from_numpy(poses)).abs().max()) > 1e-4
+  objs = []
+  for k, n in enumerate((5, 0, 7)):
+    p = sc['grid'][10 * k:10 * k + n].astype(np.float32).copy()
+    p[:, :3, 3] = util.hypotheses(sc, 1)[0, :3, 3] + np.float32(0.004 * k)
+    objs.append(dict(rgb=sc['rgb'], xyz_map=xyz, K=sc['K'], mesh_tensors=mt, mesh_diameter=sc['diameter'], ob_in_cams=p))
+  plain = r.predict_multi([dict(o, shared_translation=False) for o in objs], iteration=2)
+  once = r.predict_multi(objs, iteration=2)
+  assert torch.equal(plain, once) and len(once) == 12
+
+
 def test_schedules_and_kernel_forms_are_bit_identical():
   """Schedules and kernel forms that claim bit-identical results (one process each: the knobs are read once): the two sides of encodeA as
   one chain instead of two (FP_ONE_CHAIN=1), the trunk as one batch instead of two halves on two streams (FP_TRUNK_STREAMS=1), both heads
   on one stream (FP_HEADS_SERIAL=1), the 128 -> 128 layers on the general 3x3 kernel instead of the band form (FP_C128_BAND=0), the
   in-projections on the 64-token kernel instead of tok_qkv.hip (FP_QKV64=1), 512-pixel tiles only in the 3x3 kernel (FP_HALO_TAIL=0), the tail
-  of a refinement pass (token means of both heads, pose update, next crop windows) as four launches instead of one (FP_TAIL_SPLIT=1).  The
+  of a refinement pass (token means of both heads, pose update, next crop windows) as four launches instead of one (FP_TAIL_SPLIT=1), the
+  rasteriser of one or two hypotheses as three launches instead of one (FP_RENDER_SOLO=0), the observed side of a first iteration per
+  hypothesis instead of once per object (FP_NO_SHARED_B=1).  The
   fused passes at 1, 2, 8, 40, 56 and 100 hypotheses (tests/tools/variant_digest.py) must print the digests of the default build."""
   import json, os, subprocess, sys
   script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tools', 'variant_digest.py')
@@ -487,5 +524,6 @@ def test_schedules_and_kernel_forms_are_bit_identical():
     return json.loads([l for l in r.stdout.splitlines() if l.startswith('DIGEST ')][-1][7:])
   ref = digests({})
   assert len(set(ref.values())) == len(ref)
-  for knobs in ({'FP_ONE_CHAIN': '1'}, {'FP_TRUNK_STREAMS': '1', 'FP_HEADS_SERIAL': '1'}, {'FP_C128_BAND': '0', 'FP_QKV64': '1'}, {'FP_HALO_TAIL': '0', 'FP_TAIL_SPLIT': '1'}):
+  for knobs in ({'FP_ONE_CHAIN': '1'}, {'FP_TRUNK_STREAMS': '1', 'FP_HEADS_SERIAL': '1'}, {'FP_C128_BAND': '0', 'FP_QKV64': '1'}, {'FP_HALO_TAIL': '0', 'FP_TAIL_SPLIT': '1'},
+                {'FP_RENDER_SOLO': '0', 'FP_NO_SHARED_B': '1'}):
     assert digests(knobs) == ref, knobs

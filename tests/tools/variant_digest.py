@@ -15,7 +15,7 @@ ob = objects[0]
 out = {}
 for n in (1, 2, 8, 40, 56, 100):
   refined = est.refiner.predict_multi([dict(rgb=ob['rgb'], xyz_map=ob['xyz'], K=ob['K'], mesh_tensors=est.mesh_tensors, mesh_diameter=est.diameter,
-                                            ob_in_cams=ob['poses'][:n])], iteration=2)
+                                            ob_in_cams=ob['poses'][:n], shared_translation=True)], iteration=2)      # (the hypotheses of a registration: FP_NO_SHARED_B=1 must not change a bit)
   feats = est.scorer.extract_features_multi([dict(rgb=ob['rgb'], depth=ob['depth'], K=ob['K'], mesh_tensors=est.mesh_tensors, mesh_diameter=est.diameter,
                                                   ob_in_cams=refined)])
   torch.cuda.synchronize()
