@@ -470,7 +470,11 @@ def main(argv=None):
                              ('' if world == 1 else f'; hypotheses cut into {world} contiguous shards of <= {math.ceil(N_HYP / world)}, one RCCL '
                                                     f'all-gather of [feature|pose] rows, cross-hypothesis tail + argmax on every rank'),
                  'hypotheses_per_object': N_HYP, 'objects': 1, 'est_refine_iter': ITER, 'parallelism': f'hyp-shard x{world}',
-                 'weights': 'seeded random (reference state_dict layout)'},
+                 'weights': 'seeded random (reference state_dict layout)',
+                 'first_iteration_observed_side': 'one crop per object: the 252 hypotheses of a registration share ONE translation (src/estimater.py:126-135), so '
+                                                  'the observed crop of refinement iteration 1 and its way through encodeA are computed once instead of 252 times '
+                                                  '(FP_REFINE_SHARED_TRANSLATION; same kernels, poses bit-identical to the per-hypothesis form: '
+                                                  'tests/test_gpu_pipeline.py::test_shared_translation_first_pass_is_bit_identical; FP_NO_SHARED_B=1 turns it off)'},
       'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_halo_dma_kernel + conv3x3_s1_band_kernel (the 3x3 stride-1 convolutions, 93 % of the conv FLOPs; the band form runs the 128 -> 128 layers, bit-identical)',
                    'achieved': achieved, 'peak': PEAK_F16_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F16_TFLOPS,
                    'launches': conv['launches'], 'flops_per_launch': conv['flops'] / max(conv['launches'], 1),
@@ -487,9 +491,16 @@ def main(argv=None):
       'phases_ms_per_rank': [dict(zip(('local', 'allgather', 'tail'), [float(x) for x in p.tolist()])) for p in ph_all],
     }
     # SURVEY 8(d) / BASELINE.md section 4: the step as a fraction of the MFMA roofline, and the render + crop stage against the HBM roofline
-    step_flops = 141.7e9 * N_HYP                  # (5 x 23.95 + 21.94) GFLOP per hypothesis
-    out['roofline']['step_frac'] = step_flops / (dt / args.steps) / 1e12 / PEAK_F16_TFLOPS
-    out['roofline']['step_tflops'] = step_flops / (dt / args.steps) / 1e12
+    step_flops = 141.7e9 * N_HYP                  # (5 x 23.95 + 21.94) GFLOP per hypothesis - the reference's work
+    # executed: the observed side of iteration 1 runs encodeA once per object (stem 0.241 + 64->128 stride 2 0.236 + four 128->128 layers 1.887 GFLOP
+    # per image) instead of once per hypothesis, unless FP_NO_SHARED_B is set
+    shard_hyp = math.ceil(N_HYP / world)
+    executed = step_flops - (0.0 if os.environ.get('FP_NO_SHARED_B') else 2.364e9 * (shard_hyp - 1) * world)
+    out['roofline']['step_frac'] = executed / (dt / args.steps) / 1e12 / PEAK_F16_TFLOPS
+    out['roofline']['step_tflops'] = executed / (dt / args.steps) / 1e12
+    out['roofline']['step_frac_reference_flops'] = step_flops / (dt / args.steps) / 1e12 / PEAK_F16_TFLOPS
+    out['roofline']['step_note'] = ('step_frac = EXECUTED TFLOP per step / time / peak; step_frac_reference_flops counts the reference\'s 141.7 GFLOP per hypothesis '
+                                    '(SURVEY 8(d)), of which the shared observed side of iteration 1 is computed once per object here')
     rc = [classes[c] for c in ('render', 'crop') if c in classes]
     if len(rc) == 2:
       b = sum(c['bytes_written_per_step'] for c in rc)

@@ -800,6 +800,8 @@ RenderPlan render_plan(int N, int V, int F, int Ho, int Wo, int num_cu) {
   while (S < 4 && Ho / (S * 2) >= 8) S *= 2;
   // (measured, 160x160 crops of the 16k-face mesh, strips 6 -> 12: 24 hypotheses 58 -> 49 us, 32: 72 -> 62, 40: 72 -> 78, 63: 92 -> 100)
   while ((size_t)N * S * 5 <= (size_t)num_cu * 4 && S < 16 && Ho / (S * 2) >= 8) S *= 2;
+  static const int force_s = getenv("FP_RENDER_S") ? atoi(getenv("FP_RENDER_S")) : 0;      // experiments: strips per hypothesis
+  if (force_s > 0 && (Ho + force_s - 1) / force_s <= rows_max) S = force_s;
   p.strip_rows = (Ho + S - 1) / S;
   p.S = (Ho + p.strip_rows - 1) / p.strip_rows;
   p.lds_bytes = (size_t)p.strip_rows * Wo * 8 + ((((size_t)p.strip_rows * Wo * 2) + 15) & ~(size_t)15) + p.a_lds;
