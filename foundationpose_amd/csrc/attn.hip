@@ -388,11 +388,169 @@ __global__ __launch_bounds__(FA_THREADS, 2) void attention_kernel(const f16 *__r
 #endif
 }
 
-void attn_kernel_lds(std::vector<KernelLds> &v) { v.push_back({(const void *)attention_kernel, (int)FA_LDS_BYTES}); }
+// The same attention for ONE or TWO hypotheses (a tracking frame, src/estimater.py:250-268).  There the kernel above is 8 workgroups whose
+// waves each walk all seven key blocks of their 32 queries one after the other behind a 17 k-cycle start-up: 19 us for 0.33 GFLOP.
+// Here a workgroup is one (hypothesis, head, 32-query tile) - 52 per hypothesis - and its seven waves take ONE key block of 64 each
+// (split-K attention): S^T = K Q^T, a block-local softmax (maximum m_w, sum l_w, P in fp16 relative to m_w), O_w^T = V^T P^T, all operands
+// through a wave-private LDS area (coalesced loads, fragments by ds_read_b128), then the seven partial results are merged through LDS:
+// m = max m_w, O = sum_w 2^((m_w - m) c) O_w / sum_w 2^((m_w - m) c) l_w.  Same products and the same fp16 rounding of P as above, relative
+// to the block's maximum instead of the running one: a summation order of its own (the few-image size class, like conv_small.hip).
+#define FS_WAVES 7
+#define FS_KP 136                                  // halfs per key row of a wave's K block in LDS (128 dims + 8: conflict-free fragment reads)
+#define FS_VP 72                                   // halfs per dim row of its V^T block (64 keys + 8)
+#define FS_AREA_BYTES (AT_DH * FS_VP * 2)          // a wave's LDS area: K block (64 x 136 halfs), then V^T block (128 x 72), then its partial O^T (128 x 32 floats)
+#define FS_LDS_BYTES (FS_WAVES * FS_AREA_BYTES + 2 * FS_WAVES * 32 * 4)
+static_assert(64 * FS_KP * 2 <= FS_AREA_BYTES && AT_DH * 32 * 4 <= FS_AREA_BYTES, "attention_small: wave area");
+__global__ __launch_bounds__(FS_WAVES * 64) void attention_small_kernel(const f16 *__restrict__ qk, const f16 *__restrict__ vt, int T, f16 *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char fs_lds[];     // per wave: K block -> V^T block -> partial O^T [dim][query]; then [wave][query] m and l
+  float *fs_m = reinterpret_cast<float *>(fs_lds + FS_WAVES * FS_AREA_BYTES), *fs_l = fs_m + FS_WAVES * 32;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+  const int nqt = (T + 31) >> 5, nkb = (T + 63) >> 6;
+  const int qt = blockIdx.x % nqt, h = (blockIdx.x / nqt) & 3, b = blockIdx.x / (nqt * 4);
+  const float c2 = 0.08838834764831845f * 1.4426950408889634f;      // log2(e) / sqrt(128)
+  f16 *area = reinterpret_cast<f16 *>(fs_lds + (size_t)w * FS_AREA_BYTES);
+  if (w < nkb) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    // K block and V^T block of this wave: coalesced 16-byte loads (a key row is 256 contiguous bytes, a dim row of the block 128), all
+    // requested up front; (first form, measured: the fragments as per-lane gathers, 40 per wave at the L1's tag rate: 12.3 us)
+    u32x4 kq[16], vq[16];
+    {
+      const f16 *kbase = qk + (size_t)b * T * 1024 + 512 + h * AT_DH;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = lane + 64 * u, key = min(w * 64 + (i >> 4), T - 1);       // rows past T repeat the last one (masked below)
+        kq[u] = *reinterpret_cast<const u32x4 *>(kbase + (size_t)key * 1024 + (i & 15) * 8);
+      }
+      const f16 *vbase = vt + ((size_t)b * 4 + h) * AT_DH * AT_TP;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = lane + 64 * u, col = min(w * 64 + (i & 7) * 8, 408);      // chunks past the image's zero pad read its last one (P = 0 there)
+        vq[u] = *reinterpret_cast<const u32x4 *>(vbase + (size_t)(i >> 3) * AT_TP + col);
+      }
+    }
+    half8 qf[8];
+    {
+      const f16 *qrow = qk + ((size_t)b * T + min(qt * 32 + lr, T - 1)) * 1024 + h * AT_DH + lh * 8;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const half8 *>(qrow + s * 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = lane + 64 * u;
+      *reinterpret_cast<u32x4 *>(area + (i >> 4) * FS_KP + (i & 15) * 8) = kq[u];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // (the wave reads what it wrote itself: no barrier)
+    half8 kf[2][8];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) kf[kt][s] = *reinterpret_cast<const half8 *>(area + (kt * 32 + lr) * FS_KP + s * 16 + lh * 8);
+    floatx16 sacc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][s], qf[s], sacc[kt], 0, 0, 0);
+    }
+    // keys >= T: score -1e30 -> out of the maximum, exp2 -> exactly 0
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = w * 64 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sacc[kt][r] = key < T ? sacc[kt][r] : -1.0e30f;
+      }
+    float bm = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) bm = fmaxf(bm, fmaxf(sacc[0][r], sacc[1][r]));
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    const float nmc = -bm * c2;
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kt][r], c2, nmc));
+        sacc[kt][r] = e;
+        ps += e;
+      }
+    ps += __shfl_xor(ps, 32);
+    // the K fragments are in registers: the area takes the V^T block (rows = dims, the block's 64 keys in the image's token order)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = lane + 64 * u;
+      *reinterpret_cast<u32x4 *>(area + (i >> 3) * FS_VP + (i & 7) * 8) = vq[u];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    floatx16 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      if (w * 64 + kt * 32 >= T) continue;                    // (wave-uniform) a key tile past T: P is exactly 0
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        half8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (f16)sacc[kt][8 * s2 + j];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const half8 *>(area + (dt * 32 + lr) * FS_VP + kt * 32 + s2 * 16 + lh * 8), pf,
+                                                            oacc[dt], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // the V^T block is read: the area takes the partial O^T
+    float *po = reinterpret_cast<float *>(area) + lr;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) po[(dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32] = oacc[dt][r];
+    if (lh == 0) fs_m[w * 32 + lr] = bm, fs_l[w * 32 + lr] = ps;
+  }
+  __syncthreads();
+  if (tid >= 256) return;
+  const int ql = tid & 31, dg = tid >> 5, q = qt * 32 + ql;        // query ql, dims 16 dg .. + 16
+  if (q >= T) return;
+  float m = fs_m[ql];
+  for (int k = 1; k < nkb; ++k) m = fmaxf(m, fs_m[k * 32 + ql]);
+  float l = 0.f, o[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) o[i] = 0.f;
+  for (int k = 0; k < nkb; ++k) {
+    const float sc = __builtin_amdgcn_exp2f((fs_m[k * 32 + ql] - m) * c2);
+    l += fs_l[k * 32 + ql] * sc;
+    const float *pk = reinterpret_cast<const float *>(fs_lds + (size_t)k * FS_AREA_BYTES) + dg * 16 * 32 + ql;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = fmaf(pk[i * 32], sc, o[i]);
+  }
+  const float inv = 1.f / l;
+  half8 h0, h1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h0[i] = (f16)(o[i] * inv), h1[i] = (f16)(o[8 + i] * inv);
+  f16 *orow = out + ((size_t)b * T + q) * 512 + h * AT_DH + dg * 16;
+  *reinterpret_cast<half8 *>(orow) = h0;
+  *reinterpret_cast<half8 *>(orow + 8) = h1;
+}
+
+void attn_kernel_lds(std::vector<KernelLds> &v) {
+  v.push_back({(const void *)attention_kernel, (int)FA_LDS_BYTES});
+  v.push_back({(const void *)attention_small_kernel, (int)FS_LDS_BYTES});
+}
 
 int launch_attention(fp_ctx *ctx, const f16 *qk, const f16 *vt, int B, int T, f16 *out, hipStream_t s) {
   FP_REQUIRE(T > 0 && T <= AT_MAXT, "attention: T=%d must be in [1,%d]", T, AT_MAXT);
   if (B == 0) return FP_OK;
+  static const int small_max = getenv("FP_ATTN_SMALL") ? atoi(getenv("FP_ATTN_SMALL")) : 2;      // hypotheses up to which the split-K form runs (0: off)
+  if (B <= small_max) {
+    ProfScope ps(ctx, s, "attention", 4.0 * B * 4 * (double)T * T * AT_DH);
+    hipLaunchKernelGGL(attention_small_kernel, dim3(((T + 31) / 32) * 4 * B), dim3(FS_WAVES * 64), FS_LDS_BYTES, s, qk, vt, T, out);
+    FP_CHECK_HIP(hipGetLastError());
+    return FP_OK;
+  }
   const int n_items = ((T + FA_QB - 1) / FA_QB) * 4 * B;
   const int grid = n_items < ctx->num_cu ? n_items : ctx->num_cu;        // one persistent workgroup per CU (152 KB of LDS each)
   ProfScope ps(ctx, s, "attention", 4.0 * B * 4 * (double)T * T * AT_DH);
