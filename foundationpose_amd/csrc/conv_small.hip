@@ -25,27 +25,30 @@
 
 namespace {
 
-constexpr int SM_NW = 8;       // waves per workgroup = shares of the input channels
+constexpr int SM_NW = 8;       // waves per workgroup = shares of the input channels (4 for the 64-channel layer: 16 channels per wave)
 constexpr int SM_LD = 36;      // floats per pixel row of a partial tile in LDS (32 couts + 4: 16-byte rows, spread over the banks)
 
-template <int KS, int HW, int ST>
+template <int KS, int HW, int ST, int NW = SM_NW>
 struct SmallCfg {
-  static constexpr int CIN = 128 * KS;
+  static constexpr int CIN = NW * 16 * KS;
   static constexpr int PITCH = CIN + 8;                 // halfs per staged pixel
   // input pixels (flat NHWC index) from the first tap of output pixel m0 to the last tap of m0 + 31.  Stride 1: m0 - HW - 1 .. m0 + 31 + HW + 1.
   // Stride 2 (40x40 in, 20x20 out): 31 output pixels on are one output row and 11 columns, or two rows on and 9 columns back (a step to the
   // next row - or into the next image - is 2 HW input pixels): at most 4 HW - 18 input pixels on, + the taps' HW + 1 on either side
-  static constexpr int SPAN = ST == 1 ? 32 + 2 * HW + 2 : 4 * HW - 2 * (HW - 31) + 1 + 2 * HW + 2;
-  static_assert(ST == 1 || (ST == 2 && HW == 40), "stride 2: 40x40 -> 20x20");
+  // (80x80 in, 40x40 out: one output row and 9 columns back at most: 2 HW - 18 input pixels on)
+  static constexpr int HO = HW / ST;
+  static constexpr int DMAX = ST == 1 ? 31 : (31 >= HO ? 4 * HW + 2 * (31 - 2 * HO) : 2 * HW + 2 * (31 - HO));
+  static constexpr int SPAN = DMAX + 1 + 2 * HW + 2;
+  static_assert(ST == 1 || (ST == 2 && HW % 2 == 0 && 2 * HO >= 31), "stride 2: at most two output rows per tile");
   static constexpr int BAND_BYTES = (SPAN + 1) * PITCH * 2;      // + the zero row
-  static constexpr int PART_BYTES = SM_NW * 32 * SM_LD * 4;
+  static constexpr int PART_BYTES = NW * 32 * SM_LD * 4;
   static constexpr int LDS_BYTES = BAND_BYTES > PART_BYTES ? BAND_BYTES : PART_BYTES;
 };
 
 // KS 16-channel steps per tap and wave: Cin = 128 KS; HW x HW input maps, stride ST (1 or 2: HW/2 x HW/2 output maps)
-template <int KS, int HW, int ST>
-__global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, const f16 *__restrict__ wsm) {
-  using C = SmallCfg<KS, HW, ST>;
+template <int KS, int HW, int ST, int NW = SM_NW>
+__global__ __launch_bounds__(NW * 64) void conv3x3_small_kernel(ConvArgs p, const f16 *__restrict__ wsm) {
+  using C = SmallCfg<KS, HW, ST, NW>;
   constexpr int HO = HW / ST;
   extern __shared__ __attribute__((aligned(16))) f16 band[];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
@@ -62,12 +65,12 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
   const int pb = in_index(m0) - HW - 1, n_in = p.Nimg * HW * HW;
   {
     constexpr int PPR = C::CIN / 8;                     // 16-byte pieces per pixel
-    constexpr int NP = C::SPAN * PPR, IT = (NP + SM_NW * 64 - 1) / (SM_NW * 64);
+    constexpr int NP = C::SPAN * PPR, IT = (NP + NW * 64 - 1) / (NW * 64);
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v[IT];
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
-      const int i = tid + u * (SM_NW * 64), pl = i / PPR, c8 = i - pl * PPR, pix = pb + pl;
+      const int i = tid + u * (NW * 64), pl = i / PPR, c8 = i - pl * PPR, pix = pb + pl;
       // (rows of the range in front of the first image or behind the last hold whatever pixel 0 holds: no tap reads them - a tap outside its
       // image reads the zero row -, and a select on the loaded value would make the wave wait for the load before it requests the next)
       const bool ok = i < NP && pix >= 0 && pix < n_in;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
     // ---- every weight fragment of this wave: 9 KS coalesced 1-KB loads, requested BEHIND the band's loads (which the first MFMA needs
     // first) and in flight across the band's way through LDS and the barrier; the K loop consumes them in the order they arrive
     {
-      const f16 *wb = wsm + ((size_t)(ct * SM_NW + w) * 9 * KS) * 512 + lane * 8;
+      const f16 *wb = wsm + ((size_t)(ct * NW + w) * 9 * KS) * 512 + lane * 8;
 #pragma unroll
       for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
     }
 #pragma unroll
     for (int u = 0; u < IT; ++u) {
-      const int i = tid + u * (SM_NW * 64), pl = i / PPR, c8 = i - pl * PPR;
+      const int i = tid + u * (NW * 64), pl = i / PPR, c8 = i - pl * PPR;
       if (i < NP) *reinterpret_cast<u32x4 *>(&band[pl * C::PITCH + c8 * 8]) = v[u];
     }
     if (tid < PPR) *reinterpret_cast<u32x4 *>(&band[C::SPAN * C::PITCH + tid * 8]) = u32x4{0u, 0u, 0u, 0u};
@@ -123,14 +126,14 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
   for (int rg = 0; rg < 4; ++rg)
     *reinterpret_cast<float4 *>(&part[w][lr][rg * 8 + lh * 4]) = make_float4(acc[rg * 4 + 0], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]);
   __syncthreads();
-  if (tid >= 256) return;
+  if (NW * 64 > 256 && tid >= 256) return;
   // 256 threads: pixel tid / 8, four couts each; the waves' shares in wave order, then bias, residual, ReLU, positional embedding
   const int px = tid >> 3, c4 = (tid & 7) * 4;
   const int mo = m0 + px;
   if (mo >= p.M) return;
   float4 v = *reinterpret_cast<const float4 *>(&part[0][px][c4]);
 #pragma unroll
-  for (int s = 1; s < SM_NW; ++s) {
+  for (int s = 1; s < NW; ++s) {
     const float4 q = *reinterpret_cast<const float4 *>(&part[s][px][c4]);
     v.x += q.x, v.y += q.y, v.z += q.z, v.w += q.w;
   }
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(SM_NW * 64) void conv3x3_small_kernel(ConvArgs p, c
 }
 
 // [Cout][9][Cin] -> per (cout tile of 32, wave, tap, 16-channel step) one block of 64 lanes x 8 halfs: lane (lh, lr) holds
-// w[cout tile * 32 + lr][tap][wave * Cin/8 + lh * Cin/16 + 8 step .. + 8]
-__global__ __launch_bounds__(256) void small_pack_kernel(const f16 *__restrict__ w, int Cout, int Cin, int Kpad, f16 *__restrict__ out) {
-  const int KS = Cin / 128;
+// w[cout tile * 32 + lr][tap][wave * Cin/nw + lh * Cin/(2 nw) + 8 step .. + 8]  (nw waves: 8, or 4 for 64 input channels)
+__global__ __launch_bounds__(256) void small_pack_kernel(const f16 *__restrict__ w, int Cout, int Cin, int Kpad, int nw, f16 *__restrict__ out) {
+  const int KS = Cin / (16 * nw);
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, total = (long long)Cout * 9 * Cin / 8;
   if (idx >= total) return;
   const int lane = (int)(idx & 63);
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void small_pack_kernel(const f16 *__restrict__
   blk /= KS;
   const int tap = (int)(blk % 9);
   blk /= 9;
-  const int wv = (int)(blk % SM_NW), ct = (int)(blk / SM_NW);
+  const int wv = (int)(blk % nw), ct = (int)(blk / nw);
   const int lr = lane & 31, lh = lane >> 5;
   const f16 *src = w + (size_t)(ct * 32 + lr) * Kpad + tap * Cin + wv * (16 * KS) + lh * (8 * KS) + j * 8;
   *reinterpret_cast<half8 *>(out + idx * 8) = *reinterpret_cast<const half8 *>(src);
@@ -179,20 +182,21 @@ void conv_small_kernel_lds(std::vector<KernelLds> &v) {
   v.push_back({(const void *)conv3x3_small_kernel<2, 40, 1>, SmallCfg<2, 40, 1>::LDS_BYTES});
   v.push_back({(const void *)conv3x3_small_kernel<4, 20, 1>, SmallCfg<4, 20, 1>::LDS_BYTES});
   v.push_back({(const void *)conv3x3_small_kernel<2, 40, 2>, SmallCfg<2, 40, 2>::LDS_BYTES});
+  v.push_back({(const void *)conv3x3_small_kernel<1, 80, 2, 4>, SmallCfg<1, 80, 2, 4>::LDS_BYTES});
 }
 
 size_t small_packed_halfs(int Cout, int Cin) { return (size_t)Cout * 9 * Cin; }
 
 int small_pack_weights(const f16 *d_w, int Cout, int Cin, int Kpad, f16 *d_out, hipStream_t s) {
-  FP_REQUIRE((Cin == 128 || Cin == 256 || Cin == 512) && Cout % 32 == 0 && Kpad >= 9 * Cin, "small_pack_weights: Cout=%d Cin=%d unsupported", Cout, Cin);
+  FP_REQUIRE((Cin == 64 || Cin == 128 || Cin == 256 || Cin == 512) && Cout % 32 == 0 && Kpad >= 9 * Cin, "small_pack_weights: Cout=%d Cin=%d unsupported", Cout, Cin);
   const long long total = (long long)Cout * 9 * Cin / 8;
-  hipLaunchKernelGGL(small_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_w, Cout, Cin, Kpad, d_out);
+  hipLaunchKernelGGL(small_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_w, Cout, Cin, Kpad, Cin == 64 ? 4 : SM_NW, d_out);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;
 }
 
-// The layers this form runs: the 3x3 stride-1 layers of the trunks (128 / 256 channels on 40x40 maps, 512 on 20x20) and the 256 -> 512
-// stride-2 layer (40x40 -> 20x20) in the network passes
+// The layers this form runs: the 3x3 stride-1 layers of the trunks (128 / 256 channels on 40x40 maps, 512 on 20x20) and the two
+// stride-2 layers (64 -> 128 on 80x80, 256 -> 512 on 40x40) in the network passes
 // of one or two hypotheses, and stand-alone launches of at most FP_SMALL_MAX_WG workgroups (default 2 per CU), when the caller holds the
 // packed weights (ConvArgs::wsm).  FP_SMALL=0: off (A/B timing).
 bool conv_small_shape(const ConvArgs &a, int num_cu) {
@@ -200,7 +204,8 @@ bool conv_small_shape(const ConvArgs &a, int num_cu) {
   static const int max_wg = getenv("FP_SMALL_MAX_WG") ? atoi(getenv("FP_SMALL_MAX_WG")) : 0;
   if (!on) return false;
   const bool s1 = a.stride == 1 && a.Ho == a.H && a.Wo == a.W && ((a.W == 40 && (a.Cin == 128 || a.Cin == 256)) || (a.W == 20 && a.Cin == 512));
-  const bool s2 = a.stride == 2 && a.W == 40 && a.Ho == 20 && a.Wo == 20 && a.Cin == 256;       // the 256 -> 512 stride-2 layer between the two halves of encodeAB
+  const bool s2 = a.stride == 2 && ((a.W == 40 && a.Ho == 20 && a.Wo == 20 && a.Cin == 256) ||   // the 256 -> 512 stride-2 layer between the two halves of encodeAB
+                                    (a.W == 80 && a.Ho == 40 && a.Wo == 40 && a.Cin == 64));     // the 64 -> 128 stride-2 layer behind the stem
   if (!(a.KH == 3 && a.KW == 3 && a.pad == 1 && a.H == a.W && a.out_mode == 0 && (s1 || s2) && a.Cout % 32 == 0 && a.Kpad == 9 * a.Cin &&
         a.out_ld % 4 == 0 && a.coff_hi % 4 == 0 && a.M > 0))
     return false;
@@ -217,7 +222,9 @@ int launch_conv_small(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
   constexpr int l1 = SmallCfg<1, 40, 1>::LDS_BYTES, l2 = SmallCfg<2, 40, 1>::LDS_BYTES, l4 = SmallCfg<4, 20, 1>::LDS_BYTES, l2s = SmallCfg<2, 40, 2>::LDS_BYTES;
   static_assert(l2s <= 160 * 1024 - 1024, "stride-2 band fits LDS");
   const dim3 g(grid), b(SM_NW * 64);
-  if (a.stride == 2) hipLaunchKernelGGL((conv3x3_small_kernel<2, 40, 2>), g, b, l2s, s, a, a.wsm);
+  constexpr int l1s = SmallCfg<1, 80, 2, 4>::LDS_BYTES;
+  if (a.stride == 2 && a.Cin == 64) hipLaunchKernelGGL((conv3x3_small_kernel<1, 80, 2, 4>), g, dim3(4 * 64), l1s, s, a, a.wsm);
+  else if (a.stride == 2) hipLaunchKernelGGL((conv3x3_small_kernel<2, 40, 2>), g, b, l2s, s, a, a.wsm);
   else if (a.Cin == 128) hipLaunchKernelGGL((conv3x3_small_kernel<1, 40, 1>), g, b, l1, s, a, a.wsm);
   else if (a.Cin == 256) hipLaunchKernelGGL((conv3x3_small_kernel<2, 40, 1>), g, b, l2, s, a, a.wsm);
   else hipLaunchKernelGGL((conv3x3_small_kernel<4, 20, 1>), g, b, l4, s, a, a.wsm);

@@ -158,7 +158,7 @@ int make_conv(fp_net *net, const SD &sd, const std::string &wkey, const std::str
     FP_TRY(s2_pack_weights(out->w, Cout, CinP, Kpad, out->wpk, nullptr, stride == 1 ? 2 : 0, stride == 1 ? 1 : 0));      // (conv_s1b.hip: 64 couts per wave group)
     FP_CHECK_HIP(hipStreamSynchronize(nullptr));
   }
-  if (K == 3 && ((stride == 1 && (CinP == 128 || CinP == 256 || CinP == 512)) || (stride == 2 && CinP == 256)) && Cout % 32 == 0 && Kpad == 9 * CinP) {
+  if (K == 3 && ((stride == 1 && (CinP == 128 || CinP == 256 || CinP == 512)) || (stride == 2 && (CinP == 256 || CinP == 64))) && Cout % 32 == 0 && Kpad == 9 * CinP) {
     void *pk = nullptr;
     FP_CHECK_HIP(hipMalloc(&pk, small_packed_halfs(Cout, CinP) * sizeof(f16)));
     net->allocs.push_back(pk);

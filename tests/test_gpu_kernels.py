@@ -515,6 +515,8 @@ def _pack_conv_weight(w, cin_pad):
   (1, 40, 40, 128, 128, 3, 1, True, True),          # conv_small.hip (a few images: 32 x 32 tiles, K split over the waves): 50 x 4 workgroups
   (3, 20, 20, 512, 512, 3, 1, True, False),         # ... tiles that straddle images, last tile partial (1200 pixels), no ReLU
   (1, 40, 40, 256, 128, 3, 1, False, True),         # ... Cout != Cin
+  (1, 80, 80, 64, 128, 3, 2, False, True),          # ... the 64 -> 128 stride-2 layer behind the stem: four waves of 16 channels, 305-pixel band
+  (2, 80, 80, 64, 128, 3, 2, True, False),          # ... tiles that straddle rows and the two images
   (1, 40, 40, 256, 512, 3, 2, False, True),         # stride 2, 72 K-steps at one hypothesis: split-K of the implicit GEMM (4 shares of 18 steps), last 64-pixel tile partial
   (4, 40, 40, 256, 512, 3, 2, False, False),        # the same at the largest batch that takes it (1600 pixels), no ReLU
   (1, 1, 1000, 512, 1024, 1, 1, False, False),     # a Linear layer (1x1, M=1000 tokens: ragged last tile)
