@@ -77,3 +77,20 @@ def test_batch_pose_data_matches_reference(golden):
   rgbA, xyzA, rgbB, xyzB = planar_views(net)
   assert rgbA.shape == (3, 3, 2, 2) and rgbA.dtype == torch.float32
   np.testing.assert_array_equal(xyzB[1, 2].numpy(), net[4, :, :, 5].float().numpy())
+
+
+def test_shared_translation_detection_is_host_only():
+  """PoseRefinePredictor._shares_translation (the hint behind FP_REFINE_SHARED_TRANSLATION): host arrays - what the reference hands to
+  predict(), src/estimater.py:215 - are compared exactly; an explicit True / False is the caller's word; a single hypothesis has nothing to
+  share.  (Device tensors are never inspected: that would synchronise; tests/test_gpu_pipeline.py covers them.)"""
+  import numpy as np
+  import torch
+  from foundationpose_amd.predict_pose_refine import PoseRefinePredictor as P
+  poses = np.tile(np.eye(4, dtype=np.float32), (5, 1, 1))
+  poses[:, :3, 3] = [0.1, -0.2, 0.7]
+  assert P._shares_translation(poses, None) and P._shares_translation(torch.from_numpy(poses), None)
+  moved = poses.copy()
+  moved[3, 0, 3] = np.nextafter(np.float32(0.1), np.float32(1))          # one ulp is not "the same translation"
+  assert not P._shares_translation(moved, None)
+  assert not P._shares_translation(poses[:1], None)
+  assert P._shares_translation(moved, True) and not P._shares_translation(poses, False)
