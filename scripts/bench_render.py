@@ -33,5 +33,15 @@ for N in [int(a) for a in sys.argv[1:]] or [252, 126, 63, 32, 1]:
   e1.record()
   torch.cuda.synchronize()
   us = e0.elapsed_time(e1) / reps * 1e3
+  if os.environ.get('FLUSH'):
+    # every launch behind a 96-MB fill (the L2s hold none of the mesh, as inside a frame behind 33 MB of weights per pass); events around the render only
+    junk = torch.empty((96 << 20,), dtype=torch.uint8, device=dev)
+    tot = 0.0
+    for _ in range(reps):
+      junk.fill_(1)
+      e0.record(); run(); e1.record()
+      torch.cuda.synchronize()
+      tot += e0.elapsed_time(e1)
+    print(f'render N={N:4d}: {tot / reps * 1e3:8.1f} us per launch behind a cache-flushing fill')
   cov = float((net[..., 5] != 0).float().mean())
   print(f'render N={N:4d}: {us:8.1f} us per launch triple  ({N * 160 * 160 * 16 / us / 1e6:6.2f} TB/s written; {cov * 100:.0f} % of the pixels covered)')
