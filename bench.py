@@ -33,6 +33,9 @@ ITER = 5
 PEAK_F16_TFLOPS = 2500.0     # MI355X dense fp16/bf16 MFMA (MI355X_MICROARCH.md)
 
 
+SHARED_HINT = True       # the refiner is told what register() knows: the hypotheses of an object share one translation on entry (False: the per-hypothesis form, timed as an extra)
+
+
 def build_job(device, n_objects, rank):
   from foundationpose_amd import synthetic as S
   from foundationpose_amd.Utils import nvdiffrast_render
@@ -76,7 +79,7 @@ def step_local(est, objects, world, rank):
   # rank for every object: each rank of an 8-GPU job handles exactly 252 hypotheses
   sl = [ranges[rotated_shard(o, rank, world)] for o in range(len(objects))]
   refined = est.refiner.predict_multi([dict(rgb=ob['rgb'], xyz_map=ob['xyz'], K=ob['K'], mesh_tensors=est.mesh_tensors,
-                                            mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b], shared_translation=True)      # (as register() does: the rotation grid around ONE guessed centre, build_job)
+                                            mesh_diameter=est.diameter, ob_in_cams=ob['poses'][a:b], shared_translation=SHARED_HINT)      # (as register() does: the rotation grid around ONE guessed centre, build_job)
                                        for ob, (a, b) in zip(objects, sl)], iteration=ITER)
   offs = [0]
   for a, b in sl:
@@ -439,6 +442,15 @@ def main(argv=None):
       dtw, _ = timed_steps(weak, args.steps, barrier, device, world)
       extras['weak_n_objects'] = {'objects': world, 'value': N_HYP * world * args.steps / dtw, 'unit': 'pose-hypotheses/sec',
                                   'ms_per_step': dtw / args.steps * 1e3, 'scaling': 'weak'}
+    # the headline workload with the observed side of iteration 1 cropped and encoded per hypothesis, as the reference's loop does (identical poses)
+    global SHARED_HINT
+    SHARED_HINT = False
+    for _ in range(args.warmup):
+      single()
+    dtp, _ = timed_steps(single, args.steps, barrier, device, world)
+    SHARED_HINT = True
+    extras['per_hypothesis_observed_side'] = {'value': N_HYP * args.steps / dtp, 'unit': 'pose-hypotheses/sec', 'ms_per_step': dtp / args.steps * 1e3,
+                                              'note': 'configs[1] / configs[2] without FP_REFINE_SHARED_TRANSLATION: iteration 1 crops and encodes the observed side once per hypothesis'}
     c3 = lambda: step(est, objects[:4], world, rank)       # configs[3]: 4 concurrent objects x 252 = 1008 hypotheses, per-object argmax
     for _ in range(args.warmup):
       c3()
