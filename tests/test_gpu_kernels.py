@@ -147,13 +147,16 @@ def test_render_full_frame_and_edge_cases(sc, fp):
                               context='metal', glctx=None)
 
 
-def test_render_solo_equals_three_launches(sc, fp):
+@pytest.mark.parametrize('textured', [False, True])
+def test_render_solo_equals_three_launches(sc, fp, textured):
   """One or two hypotheses render in ONE launch (raster.hip render_kernel<.., true>: vertex pass, per-strip classification into LDS and
   triangle pass together - a tracking frame's rasteriser); larger batches in three.  Same functions on the same inputs and an
   order-independent z-buffer: every output of a hypothesis rendered alone or in a pair equals its slice of a batch of 8, bit for bit -
   the API's maps, dr.rasterize's own output and the fused fp16 network tensor; also for a pose through the camera plane."""
   from oracle import geometry as G
   from foundationpose_amd._lib import check, k_ptr, lib, ptr, stream_ptr
+  if textured:
+    sc = util.scene(0, textured=True)
   poses = util.hypotheses(sc, 8, jitter_seed=3)
   poses[5, :3, 3] = [0.01, -0.02, 0.05]              # through the camera plane: homogeneous rasterisation, list B only
   tf = G.compute_crop_window_tf_batch(torch.from_numpy(poses), sc['K'], 1.2, (160, 160), sc['diameter'])
