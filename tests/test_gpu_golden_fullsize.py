@@ -220,7 +220,8 @@ def test_full_gain_passes_equal_the_oracle_with_the_products_roundings(name, ful
   (a) EVERY pass, ALL 252 hypotheses, no subset, full gain: iteration k of the HIP path from the d16 chain's state after k - 1 iterations
       (so both sides see the same crop window and the same pixels) against the d16 chain's state after k: max over the 252 poses < 1e-4 -
       ten times inside the tolerance and ~7 x closer than the fp32 oracle is (1.2-1.4e-4, test_every_iteration_one_step_...).  A logic
-      difference at full gain would show here exactly as it shows against the fp32 chain; precision is all that is left.
+      difference at full gain would show here exactly as it shows against the fp32 chain; precision is all that is left.  Also for the
+      first one and two hypotheses ALONE (round 5: the few-image kernels of a tracking frame run those).
   (b) CHAINED from the start hypotheses: two chains that differ by 1e-5 per pass still separate - the untrained network doubles a
       difference per iteration and the rounded crop window (src/Utils.py:577-621) flips for ~3 % of the hypotheses per iteration (a 1.3e-5 m
       difference is 0.02 px) - so no chain of ANY two implementations stays within 1e-3 on all 252 for five iterations.  Asserted on all 252:
@@ -248,6 +249,12 @@ def test_full_gain_passes_equal_the_oracle_with_the_products_roundings(name, ful
           f'(the pass moves the poses by median {np.median(moved):.2e})')
     assert np.median(moved) > 5 * D16_STEP_TOL                      # millimetre steps that depend on the crops
     assert err.max() < D16_STEP_TOL, f'{name}: pass {it}: more than the order of fp32 sums explains'
+    # the same pass for the first one and two hypotheses alone: the few-image kernels of a tracking frame (conv_small.hip, attention_small_kernel,
+    # the one-launch rasteriser) - another order of fp32 sums, the same bound
+    for sub in (1, 2):
+      few, _ = r_step.predict(ob_in_cams=np.ascontiguousarray(start[:sub]), xyz_map=c['xyz_map'], iteration=1, **kw)
+      e_few = np.abs(few.cpu().numpy() - d16[it - 1][:sub]).max()
+      assert e_few < D16_STEP_TOL, f'{name}: pass {it}, {sub} hypothesis(es) alone: {e_few:.2e}'
   # (b) chained
   window = lambda p: G.compute_crop_window_tf_batch(p, sc['K'], crop_ratio=r_step.cfg['crop_ratio'], out_size=(160, 160),
                                                     mesh_diameter=sc['diameter']).numpy()
