@@ -254,7 +254,7 @@ struct ConvArgs {
   int Nimg, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, Kpad, M;
   int relu, out_mode;  // 0 fp16 NHWC, 1 fp32 NHWC, 2 fp16 V-transposed [b][4][128][416], token t in column vt_col(t)
   int out_ld, split_m, coff_hi, post_period, tokens;
-  // split-K of the 3x3 stride-1 kernel for launches of a few workgroups (1 .. 4 hypotheses: tracking): `ksplit` workgroups share
+  // split-K of the 3x3 stride-1 kernel for launches of a few workgroups (3 .. 4 hypotheses; 1 .. 2, a tracking frame, run conv_small.hip): `ksplit` workgroups share
   // the input-channel chunks of a tile and leave fp32 partial sums in `splitk` [ksplit][M][Cout]; a finishing pass adds them in a
   // fixed order and applies bias-free epilogue (the bias rides in split 0).  0 / nullptr: off.
   float *splitk = nullptr;
@@ -281,7 +281,7 @@ int launch_conv_s2(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 bool s1b_supported(const ConvArgs &a);
 int launch_conv_s1b(fp_ctx *ctx, const ConvArgs &a, hipStream_t s);
 
-// conv_small.hip: the 3x3 stride-1 layers in launches of a few images (tracking; 1 .. 4 hypotheses): 32 x 32 tiles, K split over the waves of a workgroup
+// conv_small.hip: the 3x3 layers of the trunk in the passes of one or two hypotheses (a tracking frame): 32 x 32 tiles, K split over the waves of a workgroup
 bool conv_small_shape(const ConvArgs &a, int num_cu);     // the layer shapes and launch sizes it runs
 bool conv_small_use(const ConvArgs &a, int num_cu);       // ... and the caller holds the packed weights (ConvArgs::wsm)
 size_t small_packed_halfs(int Cout, int Cin);

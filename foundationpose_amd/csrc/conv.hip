@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs p, const f
   }
 }
 
-// Split-K form of the 3x3 stride-2 layer with the long K (256 -> 512 channels: 72 K-steps) at 1 .. 4 hypotheses, where the layer is
+// Split-K form of the 3x3 stride-2 layer with the long K (256 -> 512 channels: 72 K-steps) at 3 .. 4 hypotheses (1 .. 2: conv_small.hip; FP_SMALL=0: 1 .. 4), where the layer is
 // 28 .. 100 workgroups that each walk all of K behind one DMA round trip per step (38 us at one hypothesis): 64-pixel tiles,
 // p.ksplit workgroups per tile with an equal share of the K-steps each, fp32 sums to p.splitk, splitk_finish_kernel adds them in
 // share order (the scheme of conv3x3_halo_splitk_kernel: these batch sizes are the size class with its own last bits).
@@ -540,7 +540,7 @@ int launch_conv(fp_ctx *ctx, const ConvArgs &a, hipStream_t s) {
     if (band != 0 && (a.Cin == 128 || band == 2) && (long long)a.M > (long long)ctx->num_cu * 512 && s1b_supported(a)) return launch_conv_s1b(ctx, a, s);
   }
   if (halo) return launch_conv_halo(ctx, a, s);
-  if (a.splitk && a.ksplit > 1) {        // (conv_ksplit: the 3x3 stride-2 layer with the long K at 1 .. 4 hypotheses)
+  if (a.splitk && a.ksplit > 1) {        // (conv_ksplit: the 3x3 stride-2 layer with the long K at 3 .. 4 hypotheses; 1 .. 2 run conv_small.hip)
     FP_REQUIRE(a.KW == 3 && a.stride == 2 && a.Cout % 128 == 0 && (a.Kpad / C2_BK) % a.ksplit == 0 && a.out_mode == 0, "conv split-K: unsupported layer");
     const int n_t = ((a.M + 63) / 64) * (a.Cout / 128);
     hipLaunchKernelGGL((conv_igemm2_splitk_kernel<128, 3>), dim3(n_t * a.ksplit), dim3(256), igemm2_lds_bytes<128>(), s, a, (const f16 *)ctx->zero_page);

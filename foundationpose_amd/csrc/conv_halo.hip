@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_dma_kernel(ConvArgs p, in
 }
 
 
-// Split-K form for launches of a few workgroups (1 .. 4 hypotheses): every tile is a 128-pixel quarter tile, p.ksplit workgroups
+// Split-K form for launches of a few workgroups (3 .. 4 hypotheses; one and two run conv_small.hip since round 5, FP_SMALL=0: this form): every tile is a 128-pixel quarter tile, p.ksplit workgroups
 // per tile each take an equal share of the input-channel chunks.  At one hypothesis a 512-channel layer is 16 workgroups that
 // each walk 48 weight groups behind one DMA round trip apiece (40 us); four shares of 12 groups + the finishing pass take a third,
 // eight shares of 6 (1 and 2 hypotheses: the grid still fits the chip) another 2 % of a one-hypothesis step.
