@@ -573,7 +573,7 @@ int run_qkv(fp_ctx *ctx, const LinP *const *q, const LinP *const *k, const LinP 
     a.blk[3 * l + 1] = TokGemmBlock{k[l]->w, k[l]->bias, qk[l], 1024, 512, 0, 0};
     a.blk[3 * l + 2] = TokGemmBlock{v[l]->w, v[l]->bias, vt[l], 0, 0, 0, 1};
   }
-  return launch_tok_qkv(ctx, a, s);
+  return launch_tok_qkv(ctx, a, s, N);
 }
 
 }  // namespace
@@ -685,7 +685,7 @@ int fp_refine_forward_ab(fp_ctx *ctx, const fp_net *net, const void *d_net_in, i
 extern "C" int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const float *h_weight, const float *h_bias, int epilogue, int relu,
                                    const void *d_res, const float *h_gamma, const float *h_beta, int tokens, void *d_out, void *stream) {
   FP_REQUIRE(ctx && d_in && h_weight && h_bias && d_out, "fp_token_linear_f16: null argument");
-  FP_REQUIRE(epilogue >= TG_EPI_ROWS && epilogue <= TG_EPI_LNSUM + 2, "fp_token_linear_f16: epilogue %d unknown", epilogue);
+  FP_REQUIRE(epilogue >= TG_EPI_ROWS && epilogue <= TG_EPI_LNSUM + 4, "fp_token_linear_f16: epilogue %d unknown", epilogue);
   FP_CHECK_HIP(hipSetDevice(ctx->device));
   std::vector<f16> hw((size_t)512 * 512);
   pack_tok_weights(h_weight, hw.data());
@@ -709,9 +709,9 @@ extern "C" int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const f
     a.gamma = h_gamma ? d_g : nullptr;
     a.beta = h_beta ? d_b : nullptr;
     a.gsum = (float *)d_out;
-    if (epilogue > TG_EPI_LNSUM) {          // 4 / 5: rows / transposed V image through the 128-token kernel of the in-projections (tok_qkv.hip)
-      a.blk[0].vt = epilogue == TG_EPI_LNSUM + 2;
-      FP_TRY(launch_tok_qkv(ctx, a, (hipStream_t)stream));
+    if (epilogue > TG_EPI_LNSUM) {          // 4 / 5: rows / transposed V image through the 128-token kernel of the in-projections (tok_qkv.hip); 6 / 7: its few-image form
+      a.blk[0].vt = ((epilogue - TG_EPI_LNSUM) & 1) == 0;
+      FP_TRY(launch_tok_qkv(ctx, a, (hipStream_t)stream, epilogue > TG_EPI_LNSUM + 2 ? 1 : 0));
     } else {
       FP_TRY(launch_tok_gemm(ctx, a, epilogue, (hipStream_t)stream));
     }

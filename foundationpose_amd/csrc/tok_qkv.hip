@@ -209,9 +209,124 @@ __global__ __launch_bounds__(TQ_THREADS, 1) void tok_qkv_kernel(TokGemmArgs p, i
   }
 }
 
-void tok_qkv_kernel_lds(std::vector<KernelLds> &v) { v.push_back({(const void *)tok_qkv_kernel, TQ_LDS_BYTES}); }
+// The same in-projections for ONE or TWO hypotheses (a tracking frame, src/estimater.py:250-268).  There the kernel above is 24 units on
+// 24 CUs, each with 67 MFLOP of its own: 14.6 us, bound by the matrix pipes of a tenth of the chip.  Here a workgroup is (32 tokens,
+// block, 128 of its 512 columns) - 13 x 6 x 4 = 312 per hypothesis, two per CU - and its 8 waves are 4 quarters of K x 2 halves of the
+// columns: 16 weight fragments per wave (coalesced 1-KB loads of pack_tok_weights' image, all requested up front), the token tile -
+// 32 KB, contiguous - copied to LDS once (row pitch 512 + 8 halfs), 16 MFMAs, the four K quarters added through LDS in order, bias,
+// and the rows or the transposed V image written as the kernel above writes them.  K in four quarters: a summation order of its own (the
+// few-image size class, like conv_small.hip), not the bit pattern of tok_gemm.hip.
+#define TS_PITCH 520                               // halfs per token row in LDS
+#define TS_PLD 132                                 // floats per token row of a partial tile (128 columns + 4)
+#define TS_LDS_BYTES (4 * 32 * TS_PLD * 4)         // 4 K quarters x 32 tokens x 128 columns fp32 (67.6 KB); the token tile (33 KB) lies in the same bytes first
+__global__ __launch_bounds__(512, 2) void tok_qkv_small_kernel(TokGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ts_smem[];
+  f16 *tile = reinterpret_cast<f16 *>(ts_smem);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 31, lh = lane >> 5;
+  const int kq = w & 3, chh = w >> 2;                        // K quarter, column half (64 columns: fragments i = 2 chh, 2 chh + 1)
+  const int g = blockIdx.x & 3, b = (blockIdx.x >> 2) % p.nblk, tl = (blockIdx.x >> 2) / p.nblk;
+  const TokGemmBlock &blk = p.blk[b];
+  const int m0 = tl * 32;
+  // weights: fragment (g, k16, i) of the packed image is 64 lanes x 16 bytes
+  tq_u32x4 wf[8][2];
+  {
+    const tq_u32x4 *wp = reinterpret_cast<const tq_u32x4 *>(blk.w) + ((size_t)g * 32 + kq * 8) * 4 * 64 + (chh * 2) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) wf[k][i] = wp[(k * 4 + i) * 64];
+  }
+  // the token tile: rows m0 .. m0 + 31 (rows past M repeat the last one), 2048 pieces of 16 bytes
+  {
+    tq_u32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 512, row = i >> 6, c8 = i & 63;
+      v[u] = *reinterpret_cast<const tq_u32x4 *>(p.in + (size_t)min(m0 + row, p.M - 1) * 512 + c8 * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = tid + u * 512, row = i >> 6, c8 = i & 63;
+      *reinterpret_cast<tq_u32x4 *>(tile + row * TS_PITCH + c8 * 8) = v[u];
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (not a __syncthreads(): the weight loads stay in flight)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  floatx16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const half8 tf = *reinterpret_cast<const half8 *>(tile + lr * TS_PITCH + (kq * 8 + k) * 16 + lh * 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8 *>(&wf[k][i]), tf, acc[i], 0, 0, 0);
+  }
+  __syncthreads();                                              // the tile is read: its bytes take the partial sums [K quarter][token][column]
+  float *part = reinterpret_cast<float *>(ts_smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      *reinterpret_cast<float4 *>(part + ((size_t)kq * 32 + lr) * TS_PLD + chh * 64 + i * 32 + rg * 8 + lh * 4) =
+          make_float4(acc[i][rg * 4 + 0], acc[i][rg * 4 + 1], acc[i][rg * 4 + 2], acc[i][rg * 4 + 3]);
+  __syncthreads();
+  const int cbase = blk.coff + g * 128;
+  if (!blk.vt) {
+    // rows: thread = (token tid / 16, 8 columns): the four quarters in order, bias, ReLU, one 16-byte store
+    const int tk = tid >> 4, c8 = (tid & 15) * 8, m = m0 + tk;
+    if (m >= p.M) return;
+    float v8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v8[e] = part[(size_t)tk * TS_PLD + c8 + e];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] += part[((size_t)q * 32 + tk) * TS_PLD + c8 + e];
+    half8 hv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v8[e] + blk.bias[g * 128 + c8 + e];
+      if (blk.relu) x = fmaxf(x, 0.f);
+      hv[e] = (f16)x;
+    }
+    *reinterpret_cast<half8 *>((f16 *)blk.out + (size_t)m * blk.ld + cbase + c8) = hv;
+    return;
+  }
+  // transposed V image: thread = (channel tid & 127, group of 16 tokens (tid >> 7) & 1), threads 0 .. 255; a group lies in one hypothesis
+  if (tid >= 256) return;
+  const int ch = tid & 127, grp = tid >> 7, mg = m0 + grp * 16;
+  if (mg >= p.M) return;
+  const int bb = mg / p.tokens, t0 = mg - bb * p.tokens;          // t0 is a multiple of 16
+  const int col = cbase + ch, hh = col >> 7, d = col & 127;
+  const float bias = blk.bias[g * 128 + ch];
+  half8 lo, hi;                                                   // image order of a group of 16: tokens 0-3, 8-11 | 4-7, 12-15
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int row = grp * 16 + t;
+    float x = part[(size_t)row * TS_PLD + ch];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) x += part[((size_t)q * 32 + row) * TS_PLD + ch];
+    const f16 hx = (f16)(x + bias);
+    const int pos = vt_col(t);
+    if (pos < 8) lo[pos] = hx;
+    else hi[pos - 8] = hx;
+  }
+  f16 *rowp = (f16 *)blk.out + (((size_t)bb * 4 + hh) * 128 + d) * 416;
+  *reinterpret_cast<half8 *>(rowp + t0) = lo;
+  *reinterpret_cast<half8 *>(rowp + t0 + 8) = hi;
+  if (t0 + 16 == p.tokens)                                        // the image is 416 tokens wide: zeros behind a hypothesis' last tokens
+    for (int z = p.tokens; z < 416; z += 8) *reinterpret_cast<uint4 *>(rowp + z) = uint4{0u, 0u, 0u, 0u};
+}
 
-int launch_tok_qkv(fp_ctx *ctx, const TokGemmArgs &a, hipStream_t s) {
+void tok_qkv_kernel_lds(std::vector<KernelLds> &v) {
+  v.push_back({(const void *)tok_qkv_kernel, TQ_LDS_BYTES});
+  v.push_back({(const void *)tok_qkv_small_kernel, TS_LDS_BYTES});
+}
+
+int launch_tok_qkv(fp_ctx *ctx, const TokGemmArgs &a, hipStream_t s, int hyp) {
   FP_REQUIRE(a.in && a.M >= 0 && a.nblk >= 1 && a.nblk <= TG_MAXBLK, "tok_qkv: bad arguments");
   if (a.M == 0) return FP_OK;
   FP_REQUIRE((double)a.M * 512 * 2.0 < 4294967296.0, "tok_qkv: M=%d too large for 32-bit lane offsets", a.M);
@@ -221,11 +336,17 @@ int launch_tok_qkv(fp_ctx *ctx, const TokGemmArgs &a, hipStream_t s) {
     if (k.vt) FP_REQUIRE(a.tokens > 0 && a.tokens % 16 == 0 && a.tokens <= 416 && k.coff % 64 == 0, "tok_qkv: tokens=%d must be a multiple of 16, <= 416", a.tokens);
     else FP_REQUIRE(k.ld % 8 == 0 && k.coff % 64 == 0, "tok_qkv: bad output of block %d", b);
   }
+  ProfScope ps(ctx, s, "linear", 2.0 * (double)a.M * 512.0 * 512.0 * a.nblk);
+  static const int small_max = getenv("FP_QKV_SMALL") ? atoi(getenv("FP_QKV_SMALL")) : 2;       // hypotheses of the pass up to which the few-image form runs (0: off)
+  if (hyp > 0 && hyp <= small_max) {
+    hipLaunchKernelGGL(tok_qkv_small_kernel, dim3(((a.M + 31) / 32) * a.nblk * 4), dim3(512), TS_LDS_BYTES, s, a);
+    FP_CHECK_HIP(hipGetLastError());
+    return FP_OK;
+  }
   const int n_tiles = (a.M + TQ_ROWS - 1) / TQ_ROWS, n_units = n_tiles * a.nblk;
   int n_wg = n_units < ctx->num_cu ? n_units : ctx->num_cu;
   const int upw = (n_units + n_wg - 1) / n_wg;
   n_wg = (n_units + upw - 1) / upw;
-  ProfScope ps(ctx, s, "linear", 2.0 * (double)a.M * 512.0 * 512.0 * a.nblk);
   hipLaunchKernelGGL(tok_qkv_kernel, dim3(n_wg), dim3(TQ_THREADS), TQ_LDS_BYTES, s, a, n_units, upw);
   FP_CHECK_HIP(hipGetLastError());
   return FP_OK;

@@ -297,6 +297,8 @@ int fp_attention_f16(fp_ctx *ctx, const void *d_qk, const void *d_vt, int B, int
  *            3: sums over groups of 16 tokens of the normalised rows (before gamma / beta), fp32 [M/16][512]
  *            4 / 5: epilogues 0 / 1 through the kernel the networks' in-projections run (csrc/tok_qkv.hip: a resident 128-token
  *               tile, every column block in one launch); bit-identical to 0 / 1
+ *            6 / 7: epilogues 0 / 1 through the few-image form of that kernel (one or two hypotheses: 32-token tiles, K in four
+ *               quarters added in order - its own fp32 summation order)
  * h_weight (512x512 row-major) / h_bias / h_gamma / h_beta are host fp32; synchronises the stream. */
 int fp_token_linear_f16(fp_ctx *ctx, const void *d_in, int M, const float *h_weight, const float *h_bias, int epilogue, int relu,
                         const void *d_res, const float *h_gamma, const float *h_beta, int tokens, void *d_out, void *stream);

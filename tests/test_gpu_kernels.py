@@ -789,6 +789,39 @@ def test_token_qkv_equals_the_64_token_kernel(fp, n_hyp):
   assert float((c.float().cpu() - torch.relu(lin)).abs().max()) <= 2e-3 * float(lin.abs().max())
 
 
+@pytest.mark.parametrize('n_hyp', [1, 2])
+def test_token_qkv_few_image_form(fp, n_hyp):
+  """tok_qkv_small_kernel - the in-projections of a tracking frame (one or two hypotheses): 32-token tiles x 128 columns per workgroup, K in
+  four quarters added in order.  Another fp32 summation order than tok_gemm.hip's, so not its bit pattern: within one fp16 ulp of it on
+  nearly every element, within the fp32 reference's tolerance everywhere; the transposed V image has the same layout (token order, zero
+  pad behind the last tokens) - every element, NaN-prefilled buffers."""
+  from foundationpose_amd._lib import check, lib, ptr, stream_ptr
+  M = 400 * n_hyp
+  g = torch.Generator().manual_seed(700 + n_hyp)
+  x = torch.randn((M, 512), generator=g).half()
+  w = (torch.randn((512, 512), generator=g) * (1.0 / 512) ** 0.5).half().float()
+  b = torch.randn((512,), generator=g) * 0.1
+  x_d = x.cuda()
+
+  def run(epi, relu, out):
+    check(lib().fp_token_linear_f16(fp['ctx'].handle, ptr(x_d), M, ptr(w.numpy()), ptr(b.numpy()), epi, relu, None, None, None, 400, ptr(out), stream_ptr()))
+    return out
+  lin = x.float() @ w.T + b
+  scale = float(lin.abs().max())
+  for relu in (0, 1):
+    a = run(0, relu, torch.full((M, 512), float('nan'), dtype=torch.float16, device='cuda'))
+    c = run(6, relu, torch.full((M, 512), float('nan'), dtype=torch.float16, device='cuda'))
+    assert not bool(torch.isnan(c).any())
+    ref = torch.relu(lin) if relu else lin
+    assert float((c.float().cpu() - ref).abs().max()) <= 2e-3 * scale
+    assert float((a != c).float().mean()) < 0.05 and float((a.float() - c.float()).abs().max()) <= 4e-3 * scale      # (the same values to an fp16 ulp)
+  va = run(1, 0, torch.full((n_hyp, 4, 128, 416), float('nan'), dtype=torch.float16, device='cuda'))
+  vc = run(7, 0, torch.full((n_hyp, 4, 128, 416), float('nan'), dtype=torch.float16, device='cuda'))
+  assert not bool(torch.isnan(vc).any())
+  assert torch.equal(vc[..., 400:], torch.zeros_like(vc[..., 400:])) and torch.equal(va[..., 400:], vc[..., 400:])
+  assert float((va != vc).float().mean()) < 0.05 and float((va.float() - vc.float()).abs().max()) <= 4e-3 * scale
+
+
 @pytest.mark.parametrize('B', [3, 1, 2])
 @pytest.mark.parametrize('T', [400, 384, 230, 64, 37, 1])
 def test_attention_vs_reference(fp, T, B):
