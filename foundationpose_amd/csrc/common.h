@@ -322,6 +322,7 @@ struct TokGemmArgs {
 enum { TG_EPI_ROWS = 0, TG_EPI_VT = 1, TG_EPI_LN = 2, TG_EPI_LNSUM = 3 };
 int launch_tok_gemm(fp_ctx *ctx, const TokGemmArgs &a, int epi, hipStream_t s);
 // tok_qkv.hip: the in-projections - all blocks over a resident 128-token tile (fp16 rows or the transposed V image per block)
+int tok_qkv_small_max();        // passes of up to this many hypotheses run tok_qkv_small_kernel (FP_QKV_SMALL)
 int launch_tok_qkv(fp_ctx *ctx, const TokGemmArgs &a, hipStream_t s, int hyp = 0);      // hyp: hypotheses of the network pass (1 .. 2: tok_qkv_small_kernel; 0: a stand-alone call)
 // head_mlp.hip: out-projection + LayerNorm1 + linear1 + ReLU + linear2 + LayerNorm2 statistics of one transformer head in one launch
 struct HeadMlpArgs {

@@ -555,7 +555,7 @@ int run_qkv(fp_ctx *ctx, const LinP *const *q, const LinP *const *k, const LinP 
   a.M = N * 400;
   a.tokens = 400;
   static const bool old_form = getenv("FP_QKV64") != nullptr;          // A/B knob: the 64-token kernel, one launch for q | k, one for v (bit-identical)
-  if (old_form) {
+  if (old_form && N > tok_qkv_small_max()) {          // (the few-image form of one and two hypotheses has its own bits: the knob compares the two batch kernels)
     a.nblk = 2 * n_layers;
     for (int l = 0; l < n_layers; ++l) {
       a.blk[2 * l] = TokGemmBlock{q[l]->w, q[l]->bias, qk[l], 1024, 0, 0};

@@ -326,6 +326,11 @@ void tok_qkv_kernel_lds(std::vector<KernelLds> &v) {
   v.push_back({(const void *)tok_qkv_small_kernel, TS_LDS_BYTES});
 }
 
+int tok_qkv_small_max() {
+  static const int small_max = getenv("FP_QKV_SMALL") ? atoi(getenv("FP_QKV_SMALL")) : 2;       // hypotheses of the pass up to which the few-image form runs (0: off)
+  return small_max;
+}
+
 int launch_tok_qkv(fp_ctx *ctx, const TokGemmArgs &a, hipStream_t s, int hyp) {
   FP_REQUIRE(a.in && a.M >= 0 && a.nblk >= 1 && a.nblk <= TG_MAXBLK, "tok_qkv: bad arguments");
   if (a.M == 0) return FP_OK;
@@ -337,8 +342,7 @@ int launch_tok_qkv(fp_ctx *ctx, const TokGemmArgs &a, hipStream_t s, int hyp) {
     else FP_REQUIRE(k.ld % 8 == 0 && k.coff % 64 == 0, "tok_qkv: bad output of block %d", b);
   }
   ProfScope ps(ctx, s, "linear", 2.0 * (double)a.M * 512.0 * 512.0 * a.nblk);
-  static const int small_max = getenv("FP_QKV_SMALL") ? atoi(getenv("FP_QKV_SMALL")) : 2;       // hypotheses of the pass up to which the few-image form runs (0: off)
-  if (hyp > 0 && hyp <= small_max) {
+  if (hyp > 0 && hyp <= tok_qkv_small_max()) {
     hipLaunchKernelGGL(tok_qkv_small_kernel, dim3(((a.M + 31) / 32) * a.nblk * 4), dim3(512), TS_LDS_BYTES, s, a);
     FP_CHECK_HIP(hipGetLastError());
     return FP_OK;
